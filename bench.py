@@ -1,0 +1,228 @@
+#!/usr/bin/env python3
+"""bench.py - Mpixels/s of the embed + extract round trip at 4K on MI355X (BASELINE.json metric).
+
+One STEP = one pass of the hot path over one device-resident batch: the fused embed kernel over
+all frames of the batch, then the fused extract kernel over the stego frames it wrote
+(+ for N > 1 the RCCL gather of the extracted packed bits to rank 0).  Inputs are synthetic,
+generated on the device before the timed region.
+
+Workload at N = 1 (config.workload): BASELINE.json configs[2], the configuration the metric is
+quoted on - 3840x2160, 600 frames, 3 AC coefficients per block, delta 8, full-capacity payload.
+With --gpus N every rank runs that batch on its own frames (weak scaling; frames are
+independent units, the only exchange is the gather of extracted bits).
+
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (embed): algorithmic bytes
+per launch / its mean launch time measured with HIP events on the launch stream inside the timed
+region.  `cpu_baseline` (N = 1 only) times the oracle - the vectorised SciPy restatement of the
+reference's operator - on a bounded sample of the same frames on this box's host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+PKG_DIR = os.path.join(REPO, "secure-video-steganography-using-ecc-and-dct_amd")
+for _p in (PKG_DIR, REPO):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s achievable)
+SEED = 20250620
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--frames", type=int, default=600, help="frames per GPU per step")
+    ap.add_argument("--height", type=int, default=2160)
+    ap.add_argument("--width", type=int, default=3840)
+    ap.add_argument("--n-ac", type=int, default=3)
+    ap.add_argument("--delta", type=float, default=8.0)
+    ap.add_argument("--cpu-frames", type=int, default=6, help="frames in the CPU-baseline sample (0 = skip)")
+    return ap.parse_args()
+
+
+def main():
+    args = parse_args()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import ctypes as C
+
+    from svsdct import batch, native
+    from svsdct.native import Planes
+    lib = native.load()                      # raises if the HIP library is missing - no fallback
+    native.ensure_device(local_rank)
+
+    F, H, W, n_ac, delta = args.frames, args.height, args.width, args.n_ac, args.delta
+    planes = Planes.contiguous(F, H, W)
+    cap = batch.capacity_bits(F, H, W, n_ac)
+    nbytes = (cap + 7) // 8
+    stream = torch.cuda.current_stream().cuda_stream
+
+    gray = torch.empty((F, H, W), dtype=torch.uint8, device=dev)
+    stego = torch.empty_like(gray)
+    payload = torch.zeros(nbytes + 8 - nbytes % 4, dtype=torch.uint8, device=dev)
+    extracted = torch.zeros(nbytes + 8 - nbytes % 4, dtype=torch.uint8, device=dev)
+    first_frame = rank * F
+    native.check(lib.svs_fill_synthetic_dev(gray.data_ptr(), C.byref(planes), SEED, first_frame, 16, 224, stream),
+                 "fill_synthetic")
+    native.check(lib.svs_fill_bits_dev(payload.data_ptr(), cap, SEED, rank * cap, stream), "fill_bits")
+    gathered = None
+    if world > 1:
+        gathered = [torch.empty(nbytes, dtype=torch.uint8, device=dev) for _ in range(world)] if rank == 0 else None
+    torch.cuda.synchronize()
+
+    def step(ev=None):
+        if ev:
+            ev[0].record()
+        used = batch.embed_device(gray.data_ptr(), stego.data_ptr(), planes, delta, n_ac, payload.data_ptr(), 0, cap,
+                                  stream)
+        if ev:
+            ev[1].record()
+        got = batch.extract_device(stego.data_ptr(), planes, delta, n_ac, extracted.data_ptr(), extracted.numel(),
+                                   stream)
+        if ev:
+            ev[2].record()
+        if world > 1:
+            dist.gather(extracted[:nbytes], gathered, dst=0)     # RCCL: packed bits to rank 0, rank order
+        return used, got
+
+    for _ in range(args.warmup):
+        used, got = step()
+    assert (used, got) == (cap, cap) or args.warmup == 0
+
+    events = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(events[k])
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    embed_ms = sum(e[0].elapsed_time(e[1]) for e in events) / args.steps
+    extract_ms = sum(e[1].elapsed_time(e[2]) for e in events) / args.steps
+
+    # ---- correctness of what was just timed (outside the timed region) -------------------------
+    cnt = torch.zeros(1, dtype=torch.int64, device=dev)
+    native.check(lib.svs_bit_errors_dev(extracted.data_ptr(), payload.data_ptr(), cap, cnt.data_ptr(), stream), "ber")
+    sse = torch.zeros(F, dtype=torch.int64, device=dev)
+    native.check(lib.svs_frame_sse_dev(gray.data_ptr(), stego.data_ptr(), C.byref(planes), sse.data_ptr(), stream),
+                 "sse")
+    torch.cuda.synchronize()
+    bit_errors = int(cnt.item())
+    if world > 1:
+        t = torch.tensor([bit_errors], dtype=torch.int64, device=dev)
+        dist.all_reduce(t)
+        bit_errors = int(t.item())
+    import math
+    sse0 = int(sse[0].item())
+    psnr0 = float("inf") if sse0 == 0 else 10 * math.log10(255.0 ** 2 * H * W / sse0)
+    gather_ok = None
+    if world > 1 and rank == 0:
+        # rank 0's own slice of the gathered stream must be what it extracted
+        gather_ok = bool(torch.equal(gathered[0], extracted[:nbytes]))
+
+    result = None
+    if rank == 0:
+        pixels_per_step = world * F * H * W
+        mpix_s = pixels_per_step * args.steps / elapsed / 1e6
+        embed_bytes = F * H * W * 2 + nbytes            # read u8 + write u8 + packed payload
+        extract_bytes = F * H * W + nbytes
+        achieved = embed_bytes / (embed_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(REPO, "profiles", "hbm_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                with open(tpath) as fh:
+                    tj = json.load(fh)
+                if tj.get("frames") == F and tj.get("height") == H and tj.get("width") == W:
+                    traffic = tj.get("embed_bytes_per_launch")
+            except Exception:
+                traffic = None
+        result = {
+            "metric": "Mpixels/sec embed+extract round-trip at 4K; payload bit-error rate (must be 0)",
+            "value": mpix_s, "unit": "Mpix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{W}x{H} x {F} frames per GPU, {n_ac} AC coeffs/block, delta={delta:g}, "
+                                   f"full-capacity payload ({cap} bits per GPU), gray planes resident in HBM",
+                       "frames_per_gpu": F, "height": H, "width": W, "n_ac": n_ac, "delta": delta,
+                       "sharding": "frames" if world > 1 else "none",
+                       "collective": "rccl gather of packed bits" if world > 1 else "none"},
+            "payload_bit_errors": bit_errors, "payload_ber": bit_errors / (cap * world),
+            "psnr_frame0_db": psnr0,
+            "kernel_ms": {"embed": embed_ms, "extract": extract_ms},
+            "roofline": {"bound": "hbm", "kernel": "embed_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "algorithmic_bytes_per_launch": embed_bytes,
+                         "extract_achieved": extract_bytes / (extract_ms * 1e-3) / 1e9},
+        }
+        if gather_ok is not None:
+            result["gather_ok"] = gather_ok
+
+    # ---- CPU baseline: the oracle on a bounded sample of the same frames (rank 0, N = 1 only) ----
+    if rank == 0 and world == 1 and args.cpu_frames > 0:
+        import numpy as np
+
+        from oracle import qim_dct_oracle as orc            # checker / baseline only
+        m = min(args.cpu_frames, F)
+        sample = gray[:m].cpu().numpy()
+        per = cap // F
+        bits = np.unpackbits(payload[: (m * per + 7) // 8].cpu().numpy(), count=m * per)
+        t0 = time.perf_counter()
+        ref_stego, used = orc.batch_embed(sample, delta if delta != int(delta) else int(delta), bits, n_ac)
+        t_embed = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        ref_bits = orc.batch_extract_bits(ref_stego, delta if delta != int(delta) else int(delta), n_ac)
+        t_extract = time.perf_counter() - t0
+        cpu_mpix = m * H * W / (t_embed + t_extract) / 1e6
+        gpu_stego = stego[:m].cpu().numpy()
+        psnr_ref = orc.psnr_u8(sample[0], ref_stego[0])
+        result["cpu_baseline"] = {"value": cpu_mpix, "unit": "Mpix/s", "cores": 1, "kind": "port",
+                                  "sample": f"{m} of the {F} frames, embed {t_embed:.2f} s + extract {t_extract:.2f} s, "
+                                            f"vectorised scipy.fftpack restatement (oracle/qim_dct_oracle.py), 1 thread; "
+                                            f"host has {os.cpu_count()} logical cores"}
+        result["parity_sample"] = {
+            "frames": m,
+            "oracle_extract_of_gpu_stego_equals_payload": bool(np.array_equal(
+                orc.batch_extract_bits(gpu_stego[:1], delta if delta != int(delta) else int(delta), n_ac), bits[:per])),
+            "psnr_frame0_reference_db": psnr_ref, "psnr_frame0_delta_db": abs(psnr_ref - psnr0),
+            "pixels_differing_from_reference": int((gpu_stego != ref_stego).sum()), "pixels": int(gpu_stego.size)}
+
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0 and bit_errors != 0 and delta >= 8:
+        raise SystemExit("payload bit errors in the round trip")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,144 @@
+/*
+ * svsdct.h - C ABI of libsvsdct.so: the MI355X (gfx950) implementation of the per-frame
+ * 8x8 block-DCT / QIM embed-and-extract operator.
+ *
+ * What it replaces in the reference (erc-a/Secure-Video-Steganography-using-ECC-and-DCT):
+ *   proses_frame_qim_dct(frame, mode, delta, bit_payload_segment, ..., num_ac_coeffs_to_use)
+ *       config_and_setup.py:106-174      (the operator: mode 'embed' -> svs_embed*, 'extract' -> svs_extract*)
+ *   its two frame loops, batched:
+ *       embed_process.py:108-128         (frame k takes bits [k*cap, (k+1)*cap) of the stream)
+ *       extract_process.py:55-86,173-182 (per-frame bit strings concatenated in frame order)
+ * The reference has no FFI of its own (it is pure Python); the binding a maintainer adds is the
+ * ctypes stub shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - plain C types only; every function returns SVS_OK (0) or a negative SVS_ERR_* code and
+ *     never throws; svs_last_error() gives the message for the calling thread.
+ *   - the caller owns every buffer.  `*_dev` entry points take DEVICE pointers and a
+ *     hipStream_t (as void*; NULL = the null stream), enqueue work and return without
+ *     synchronising.  The entry points without the suffix take HOST pointers, stage through
+ *     device memory and return when the result is in the host buffers.
+ *   - frames are gray uint8 planes, H and W multiples of 8 (the reference's callers crop:
+ *     embed_process.py:94,113; extract_process.py:34,62), laid out [frame][row][col] with byte
+ *     pitches given in svs_planes.
+ *   - payload bits are packed MSB-first (numpy.packbits order): stream bit i is bit 7-(i%8) of
+ *     byte i/8.  Stream bit i of a batch belongs to global block i / n_ac (frames in order,
+ *     blocks in raster order inside a frame) and flat row-major coefficient 1 + i % n_ac of
+ *     that block (config_and_setup.py:139-140) - so numpy.unpackbits of the extract output is
+ *     the reference's '0'/'1' string.
+ *   - n_ac is clamped to [0, 63] as the reference does (config_and_setup.py:138).
+ *   - delta is passed as double: the quantiser divides in float32 by (float)delta and
+ *     requantises with q*delta rounded once to float32, which is what the reference's
+ *     `int(round(c / delta))` / `float(q * delta)` do for python int/float delta under
+ *     NumPy >= 2 (config_and_setup.py:148,156,160).
+ */
+#ifndef SVSDCT_H
+#define SVSDCT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SVS_ABI_VERSION 1
+
+#define SVS_OK 0
+#define SVS_ERR_INVALID_ARG (-1)  /* bad geometry / NULL pointer / size overflow */
+#define SVS_ERR_HIP (-2)          /* a HIP runtime call failed; see svs_last_error() */
+#define SVS_ERR_NO_DEVICE (-3)    /* no usable AMD GPU */
+#define SVS_ERR_CAPACITY (-4)     /* an output buffer is too small */
+
+/* Geometry of a batch of gray planes. */
+typedef struct svs_planes {
+    int32_t n_frames;
+    int32_t height;      /* multiple of 8 */
+    int32_t width;       /* multiple of 8 */
+    int32_t reserved;    /* set to 0 */
+    int64_t row_pitch;   /* bytes between rows, >= width, multiple of 8 */
+    int64_t frame_pitch; /* bytes between frames, >= height*row_pitch, multiple of 8 */
+} svs_planes;
+
+/* ---- library / device ------------------------------------------------------------------ */
+int svs_abi_version(void);
+const char *svs_last_error(void);
+int svs_device_count(int *count);
+/* Select the device for the calling thread (hipSetDevice) and check it is usable. */
+int svs_init(int device);
+/* Name of the architecture the device reports, e.g. "gfx950". */
+int svs_device_arch(int device, char *buf, size_t buf_len);
+
+/* ---- device memory / stream helpers for callers that do not bring their own ------------- */
+int svs_malloc(void **dev_ptr, size_t bytes);
+int svs_free(void *dev_ptr);
+int svs_memcpy_h2d(void *dev_dst, const void *host_src, size_t bytes, void *stream);
+int svs_memcpy_d2h(void *host_dst, const void *dev_src, size_t bytes, void *stream);
+int svs_memset(void *dev_dst, int value, size_t bytes, void *stream);
+int svs_stream_synchronize(void *stream);
+
+/* ---- capacity arithmetic ------------------------------------------------------------------ */
+/* bits one batch carries: n_frames * (H/8) * (W/8) * clamp(n_ac, 0, 63) */
+uint64_t svs_capacity_bits(const svs_planes *p, int n_ac);
+/* bytes svs_extract* writes for that many bits: ceil(bits / 8) */
+uint64_t svs_packed_bytes(uint64_t n_bits);
+
+/* ---- the operator: embed -----------------------------------------------------------------
+ * Replaces mode 'embed' of proses_frame_qim_dct (config_and_setup.py:117-172) for a whole batch
+ * and the offset bookkeeping of embed_process.py:116-128.
+ *   gray / stego : [n_frames] planes described by `planes` (same geometry for both); may alias.
+ *   bits_packed  : MSB-first packed payload; the first stream bit used is `bit_offset`
+ *                  (lets every rank index one shared buffer by its frame offset); the buffer
+ *                  must be 4-byte aligned and readable up to a multiple of 4 bytes.
+ *   n_bits       : bits available from bit_offset on.  min(n_bits, capacity) are embedded.
+ *                  Blocks past the budget are copied byte-identically; a block the budget ends
+ *                  in has only its first coefficients modified (config_and_setup.py:130,132,141).
+ *   n_embedded   : (host) receives min(n_bits, capacity); 0 when delta <= 0 or n_ac <= 0.
+ * delta <= 0 or n_ac <= 0: nothing can be embedded; stego = gray (deviations).
+ */
+int svs_embed_dev(const uint8_t *d_gray, uint8_t *d_stego, const svs_planes *planes,
+                  double delta, int n_ac,
+                  const uint8_t *d_bits_packed, uint64_t bit_offset, uint64_t n_bits,
+                  uint64_t *n_embedded, void *stream);
+
+int svs_embed(const uint8_t *gray, uint8_t *stego, const svs_planes *planes,
+              double delta, int n_ac,
+              const uint8_t *bits_packed, uint64_t bit_offset, uint64_t n_bits,
+              uint64_t *n_embedded);
+
+/* ---- the operator: extract ----------------------------------------------------------------
+ * Replaces mode 'extract' (config_and_setup.py:159-165,173-174) for a whole batch and the
+ * concatenation of extract_process.py:76,181.
+ *   bits_packed_out : receives svs_packed_bytes(capacity) bytes (the last byte zero padded);
+ *                     must be 4-byte aligned; out_capacity_bytes is its size.
+ *   n_bits_out      : (host) receives the capacity in bits.
+ * delta <= 0: every bit is 0 (config_and_setup.py:143-145).
+ */
+int svs_extract_dev(const uint8_t *d_gray, const svs_planes *planes, double delta, int n_ac,
+                    uint8_t *d_bits_packed_out, uint64_t out_capacity_bytes,
+                    uint64_t *n_bits_out, void *stream);
+
+int svs_extract(const uint8_t *gray, const svs_planes *planes, double delta, int n_ac,
+                uint8_t *bits_packed_out, uint64_t out_capacity_bytes, uint64_t *n_bits_out);
+
+/* ---- measurement helpers (synthetic inputs and on-device checks for bench.py / tests) ------ */
+/* value = lo + hash32(seed, first_frame + f, y, x) % span  - same hash as svsdct/synth.py */
+int svs_fill_synthetic_dev(uint8_t *d_frames, const svs_planes *planes, uint32_t seed,
+                           uint32_t first_frame, uint32_t lo, uint32_t span, void *stream);
+/* packed Bernoulli(1/2) stream, bit i = lowbias32(seed*0x632BE5AB + first_bit + i) >> 31;
+ * writes ceil(n_bits/8) bytes rounded up to a multiple of 4 (buffer must be that large). */
+int svs_fill_bits_dev(uint8_t *d_bits_packed, uint64_t n_bits, uint32_t seed,
+                      uint64_t first_bit, void *stream);
+/* per-frame sum of squared differences (exact integers) -> d_sse[n_frames] (uint64, device);
+ * PSNR = 10 log10(255^2 H W / sse)   (cv2.PSNR as used at embed_process.py:205, app.py:342) */
+int svs_frame_sse_dev(const uint8_t *d_a, const uint8_t *d_b, const svs_planes *planes,
+                      uint64_t *d_sse, void *stream);
+/* number of differing bits among the first n_bits of two packed streams -> *d_count (uint64,
+ * device, overwritten) */
+int svs_bit_errors_dev(const uint8_t *d_a_packed, const uint8_t *d_b_packed, uint64_t n_bits,
+                       uint64_t *d_count, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SVSDCT_H */

@@ -1,0 +1,272 @@
+// svs_block.hpp - per-block arithmetic of the fused block-DCT / QIM frame operator.
+//
+// Reference behaviour being implemented: proses_frame_qim_dct, config_and_setup.py:106-174.
+//
+// Everything here is plain C++ on values held in registers, compiled for the gfx950 device by
+// svs_device.hpp (the product) and - with g++ - by tests/hostemu/ (test infrastructure only: it
+// lets the CPU-only test tier and the sanitizers exercise the very same arithmetic and bit
+// bookkeeping; the shipped library has no CPU path).  Build both with -ffp-contract=off: fused
+// operations are spelled fmaf() explicitly so that host and device round identically.
+//
+// Decomposition (see DESIGN.md "Kernels"):
+//   * one LANE owns one 8x8 block; the block never leaves that lane's registers, so the
+//     separable transform needs no cross-lane traffic at all (no LDS, no shuffles) and a
+//     wavefront (64 lanes = 64 horizontally adjacent blocks) reads/writes 512 contiguous
+//     bytes per row instruction.
+//   * only the coefficient rows the payload touches are transformed: flat indices 1..n live in
+//     rows u < U = n/8 + 1 of the coefficient matrix, so the vertical pass produces U outputs
+//     per column and the horizontal pass runs on U rows (template parameter U).
+//   * embed uses linearity of the DCT: stego = trunc(clip(x + IDCT(D' - D))) where D' - D is
+//     non-zero only at the n requantised coefficients; x is the exact integer pixel, so the
+//     only rounding in the output is that of the (sparse) inverse transform.
+#pragma once
+#include <math.h>
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define SVS_HD __host__ __device__ __forceinline__
+#else
+#define SVS_HD inline
+#endif
+
+namespace svs {
+
+// one row of a block: 8 pixels as two little-endian dwords
+struct alignas(8) Row8 {
+    uint32_t x, y;
+};
+
+// cos(k*pi/16)/2 and 1/sqrt(8): the orthonormal DCT-II basis (scipy norm='ortho',
+// config_and_setup.py:135,168)
+#define SVS_A0 0.35355339059327373f
+#define SVS_C1 0.49039264020161522f
+#define SVS_C2 0.46193976625564337f
+#define SVS_C3 0.41573480615127262f
+#define SVS_C4 0.35355339059327373f
+#define SVS_C5 0.27778511650980114f
+#define SVS_C6 0.19134171618254492f
+#define SVS_C7 0.09754516100806417f
+
+// Orthonormal 8-point DCT-II, first NOUT outputs only (even/odd split, FMA form: 36 ops for
+// all eight outputs including the normalisation).
+template <int NOUT>
+SVS_HD void fdct8(const float (&x)[8], float (&X)[8]) {
+    const float s0 = x[0] + x[7], s1 = x[1] + x[6], s2 = x[2] + x[5], s3 = x[3] + x[4];
+    const float t0 = s0 + s3, t1 = s1 + s2;
+    X[0] = (t0 + t1) * SVS_A0;
+    if constexpr (NOUT > 1) {
+        const float d0 = x[0] - x[7], d1 = x[1] - x[6], d2 = x[2] - x[5], d3 = x[3] - x[4];
+        const float t2 = s0 - s3, t3 = s1 - s2;
+        X[1] = fmaf(d0, SVS_C1, fmaf(d1, SVS_C3, fmaf(d2, SVS_C5, d3 * SVS_C7)));
+        if constexpr (NOUT > 2) X[2] = fmaf(t2, SVS_C2, t3 * SVS_C6);
+        if constexpr (NOUT > 3) X[3] = fmaf(d0, SVS_C3, fmaf(d1, -SVS_C7, fmaf(d2, -SVS_C1, d3 * -SVS_C5)));
+        if constexpr (NOUT > 4) X[4] = (t0 - t1) * SVS_C4;
+        if constexpr (NOUT > 5) X[5] = fmaf(d0, SVS_C5, fmaf(d1, -SVS_C1, fmaf(d2, SVS_C7, d3 * SVS_C3)));
+        if constexpr (NOUT > 6) X[6] = fmaf(t2, SVS_C6, t3 * -SVS_C2);
+        if constexpr (NOUT > 7) X[7] = fmaf(d0, SVS_C7, fmaf(d1, -SVS_C5, fmaf(d2, SVS_C3, d3 * -SVS_C1)));
+    }
+}
+
+// Orthonormal 8-point DCT-III (inverse of the above) of a vector whose entries NIN..7 are zero.
+// SKIP0: entry 0 is known to be zero as well (row 0 of the modification matrix: DC is never
+// touched, config_and_setup.py:140).
+template <int NIN, bool SKIP0>
+SVS_HD void idct8(const float (&X)[8], float (&x)[8]) {
+    float a, b;  // even part: DC and X4
+    {
+        const float p = SKIP0 ? 0.0f : X[0] * SVS_A0;
+        if constexpr (NIN > 4) {
+            const float r = X[4] * SVS_C4;
+            a = SKIP0 ? r : p + r;
+            b = SKIP0 ? -r : p - r;
+        } else {
+            a = p;
+            b = p;
+        }
+    }
+    float e0 = a, e1 = b, e2 = b, e3 = a;
+    if constexpr (NIN > 2) {
+        float g0 = X[2] * SVS_C2, g1 = X[2] * SVS_C6;
+        if constexpr (NIN > 6) {
+            g0 = fmaf(X[6], SVS_C6, g0);
+            g1 = fmaf(X[6], -SVS_C2, g1);
+        }
+        if constexpr (SKIP0 && NIN <= 4) {
+            e0 = g0; e3 = -g0; e1 = g1; e2 = -g1;
+        } else {
+            e0 = a + g0; e3 = a - g0; e1 = b + g1; e2 = b - g1;
+        }
+    }
+    if constexpr (NIN > 1) {
+        float o0 = X[1] * SVS_C1, o1 = X[1] * SVS_C3, o2 = X[1] * SVS_C5, o3 = X[1] * SVS_C7;
+        if constexpr (NIN > 3) {
+            o0 = fmaf(X[3], SVS_C3, o0); o1 = fmaf(X[3], -SVS_C7, o1);
+            o2 = fmaf(X[3], -SVS_C1, o2); o3 = fmaf(X[3], -SVS_C5, o3);
+        }
+        if constexpr (NIN > 5) {
+            o0 = fmaf(X[5], SVS_C5, o0); o1 = fmaf(X[5], -SVS_C1, o1);
+            o2 = fmaf(X[5], SVS_C7, o2); o3 = fmaf(X[5], SVS_C3, o3);
+        }
+        if constexpr (NIN > 7) {
+            o0 = fmaf(X[7], SVS_C7, o0); o1 = fmaf(X[7], -SVS_C5, o1);
+            o2 = fmaf(X[7], SVS_C3, o2); o3 = fmaf(X[7], -SVS_C1, o3);
+        }
+        x[0] = e0 + o0; x[7] = e0 - o0;
+        x[1] = e1 + o1; x[6] = e1 - o1;
+        x[2] = e2 + o2; x[5] = e2 - o2;
+        x[3] = e3 + o3; x[4] = e3 - o3;
+    } else {
+        x[0] = e0; x[7] = e0; x[1] = e1; x[6] = e1;
+        x[2] = e2; x[5] = e2; x[3] = e3; x[4] = e3;
+    }
+}
+
+// byte B (0..3) of a dword as float: v_cvt_f32_ubyte{0..3} on the device
+template <int B>
+SVS_HD float ubyte_to_float(uint32_t w) {
+    return (float)((w >> (8 * B)) & 0xffu);
+}
+
+// np.uint8(np.clip(v, 0, 255)) - clip, then C truncation (config_and_setup.py:171) - written into
+// byte B of `old`.
+template <int B>
+SVS_HD uint32_t put_pixel(float v, uint32_t old) {
+#if defined(__HIP_DEVICE_COMPILE__) && defined(SVS_USE_CVT_PK_U8)
+    // v_cvt_pk_u8_f32: enabled only after tests/test_gpu_primitives.py showed on gfx950 that it
+    // saturates to [0,255] and truncates toward zero
+    return __builtin_amdgcn_cvt_pk_u8_f32(v, B, old);
+#else
+#if defined(__HIP_DEVICE_COMPILE__)
+    const float c = __builtin_amdgcn_fmed3f(v, 0.0f, 255.0f);
+#else
+    const float c = v < 0.0f ? 0.0f : (v > 255.0f ? 255.0f : v);
+#endif
+    const uint32_t u = (uint32_t)c;  // truncates toward zero
+    return (old & ~(0xffu << (8 * B))) | (u << (8 * B));
+#endif
+}
+
+// Forward transform of the coefficient rows u < U of one block held as 8 rows x 2 dwords.
+// D[u][v] = sum_y sum_x a(u)a(v) p[y][x] cos((2y+1)u pi/16) cos((2x+1)v pi/16)
+// (vertical axis first, as the reference does: axis=0 then axis=1, config_and_setup.py:135).
+template <int U>
+SVS_HD void forward_rows(const Row8 (&raw)[8], float (&D)[U][8]) {
+    float V[U][8];
+#define SVS_COL(X, W, B)                                                                \
+    {                                                                                   \
+        const float col[8] = {ubyte_to_float<B>(raw[0].W), ubyte_to_float<B>(raw[1].W), \
+                              ubyte_to_float<B>(raw[2].W), ubyte_to_float<B>(raw[3].W), \
+                              ubyte_to_float<B>(raw[4].W), ubyte_to_float<B>(raw[5].W), \
+                              ubyte_to_float<B>(raw[6].W), ubyte_to_float<B>(raw[7].W)}; \
+        float out[8];                                                                   \
+        fdct8<U>(col, out);                                                             \
+        _Pragma("unroll") for (int u = 0; u < U; ++u) V[u][X] = out[u];                 \
+    }
+    SVS_COL(0, x, 0) SVS_COL(1, x, 1) SVS_COL(2, x, 2) SVS_COL(3, x, 3)
+    SVS_COL(4, y, 0) SVS_COL(5, y, 1) SVS_COL(6, y, 2) SVS_COL(7, y, 3)
+#undef SVS_COL
+#pragma unroll
+    for (int u = 0; u < U; ++u) fdct8<8>(V[u], D[u]);
+}
+
+// q = int(round(c / delta)) : float32 division, round half to even (config_and_setup.py:148,160)
+SVS_HD int quant_index(float c, float delta_f) { return (int)rintf(c / delta_f); }
+
+struct QimParams {
+    float delta_f;   // (float)delta  - divisor
+    double delta_d;  // delta         - multiplier when (double)delta_f != delta
+};
+
+// 64 stream bits starting at stream bit s of an MSB-first packed buffer viewed as dwords
+// (touches at most dwords s/32 .. s/32+2, each only if below n_words)
+SVS_HD void payload_window(const uint32_t *bits, uint32_t n_words, uint64_t s, uint32_t &hi, uint32_t &lo) {
+    const uint32_t wi = (uint32_t)(s >> 5), sh = (uint32_t)(s & 31u);
+    const uint32_t w0 = __builtin_bswap32(wi < n_words ? bits[wi] : 0u);
+    const uint32_t w1 = __builtin_bswap32(wi + 1 < n_words ? bits[wi + 1] : 0u);
+    const uint32_t w2 = __builtin_bswap32(wi + 2 < n_words ? bits[wi + 2] : 0u);
+    const uint64_t a = ((uint64_t)w0 << 32) | w1, b = ((uint64_t)w1 << 32) | w2;
+    hi = (uint32_t)((a << sh) >> 32);
+    lo = (uint32_t)((b << sh) >> 32);
+}
+
+// bit i (0 = first) of the 64-bit MSB-first window hi:lo
+SVS_HD uint32_t window_bit(uint32_t hi, uint32_t lo, int i) {
+    return ((i < 32) ? (hi >> ((31 - i) & 31)) : (lo >> ((63 - i) & 31))) & 1u;
+}
+
+// bits a block takes from a budget of n_bits when its first stream bit is `first`
+// (config_and_setup.py:130,132,141)
+SVS_HD uint32_t block_budget(uint64_t first, uint64_t n_bits, uint32_t n) {
+    if (first >= n_bits) return 0;
+    const uint64_t left = n_bits - first;
+    return left < n ? (uint32_t)left : n;
+}
+
+// Embed `nb` (1..n) payload bits, taken MSB-first from hi:lo, into the block held in raw[].
+template <int U, bool DBL>
+SVS_HD void embed_block(Row8 (&raw)[8], uint32_t n, uint32_t nb, uint32_t hi, uint32_t lo, const QimParams &qp) {
+    float D[U][8];
+    forward_rows<U>(raw, D);
+
+    // QIM on flat coefficients 1..n: force the parity of round(c/delta) to the payload bit by
+    // +1 (bit 1) / -1 (bit 0), requantise (config_and_setup.py:146-156); keep only the change.
+#pragma unroll
+    for (int k = 0; k < 8 * U; ++k) {
+        const int u = k >> 3, v = k & 7;
+        float change = 0.0f;
+        if (k >= 1 && (uint32_t)k <= n) {  // wave-uniform
+            const int i = k - 1;
+            const int bit = (int)window_bit(hi, lo, i);
+            const float c = D[u][v];
+            int q = quant_index(c, qp.delta_f);
+            q += bit - (q & 1);  // parity of a negative q is non-negative in python (:150)
+            float cn;
+            if constexpr (DBL) cn = (float)((double)q * qp.delta_d);
+            else cn = (float)q * qp.delta_f;
+            change = ((uint32_t)i < nb) ? cn - c : 0.0f;
+        }
+        D[u][v] = change;
+    }
+
+    // inverse transform of the change: horizontal on the U rows, then vertical per column with
+    // U non-zero inputs, added to the integer pixels and stored with clip + truncation (:171)
+    float P[U][8];
+    idct8<8, true>(D[0], P[0]);
+#pragma unroll
+    for (int u = 1; u < U; ++u) idct8<8, false>(D[u], P[u]);
+
+#define SVS_OUTCOL(X, W, B)                                                          \
+    {                                                                                \
+        float in[8] = {0, 0, 0, 0, 0, 0, 0, 0};                                      \
+        _Pragma("unroll") for (int u = 0; u < U; ++u) in[u] = P[u][X];               \
+        float out[8];                                                                \
+        idct8<U, false>(in, out);                                                    \
+        _Pragma("unroll") for (int y = 0; y < 8; ++y)                                \
+            raw[y].W = put_pixel<B>(ubyte_to_float<B>(raw[y].W) + out[y], raw[y].W); \
+    }
+    SVS_OUTCOL(0, x, 0) SVS_OUTCOL(1, x, 1) SVS_OUTCOL(2, x, 2) SVS_OUTCOL(3, x, 3)
+    SVS_OUTCOL(4, y, 0) SVS_OUTCOL(5, y, 1) SVS_OUTCOL(6, y, 2) SVS_OUTCOL(7, y, 3)
+#undef SVS_OUTCOL
+}
+
+// Parity bits of round(c_k/delta), k = 1..n, MSB-first into hi:lo (config_and_setup.py:160-161)
+template <int U>
+SVS_HD void extract_block(const Row8 (&raw)[8], uint32_t n, float delta_f, uint32_t &hi, uint32_t &lo) {
+    float D[U][8];
+    forward_rows<U>(raw, D);
+    hi = 0;
+    lo = 0;
+#pragma unroll
+    for (int k = 1; k < 8 * U; ++k) {
+        if ((uint32_t)k <= n) {  // wave-uniform
+            const uint32_t bit = (uint32_t)quant_index(D[k >> 3][k & 7], delta_f) & 1u;
+            const int i = k - 1;
+            if (i < 32) hi |= bit << ((31 - i) & 31);
+            else lo |= bit << ((63 - i) & 31);
+        }
+    }
+}
+
+inline int rows_for(int n) { return (n >> 3) + 1; }  // coefficient rows holding flat indices 1..n
+
+}  // namespace svs

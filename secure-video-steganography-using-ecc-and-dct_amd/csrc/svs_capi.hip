@@ -1,0 +1,410 @@
+// svs_capi.hip - the C ABI declared in include/svsdct.h (host side + kernel launches).
+// Build: hipcc --offload-arch=gfx950 -O3 -shared -fPIC  (see csrc/Makefile)
+#include "svsdct.h"
+#include "svs_device.hpp"
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+
+#define SVS_HIP(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess) return fail(SVS_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+svs::FastDiv make_div(uint32_t d) {
+    // q = (n * mul) >> shift is exact for n < 2^31:  shift = 31 + ceil(log2 d), mul = ceil(2^shift / d)
+    uint32_t l = 0;
+    while ((1ull << l) < d) ++l;
+    svs::FastDiv r;
+    r.shift = 31 + l;
+    r.mul = (uint32_t)(((1ull << r.shift) + d - 1) / d);
+    r.div = d;
+    r.pad = 0;
+    return r;
+}
+
+int clamp_ac(int n_ac) { return n_ac < 0 ? 0 : (n_ac > 63 ? 63 : n_ac); }
+
+// validates the plane description and fills the kernel geometry
+int make_geometry(const svs_planes *p, int n_ac, svs::Geometry *g, uint64_t *total_blocks) {
+    if (!p) return fail(SVS_ERR_INVALID_ARG, "planes is NULL");
+    if (p->n_frames < 0 || p->height <= 0 || p->width <= 0)
+        return fail(SVS_ERR_INVALID_ARG, "bad frame geometry %d x %d x %d", p->n_frames, p->height, p->width);
+    if ((p->height % 8) || (p->width % 8))
+        return fail(SVS_ERR_INVALID_ARG, "height and width must be multiples of 8 (got %d x %d)", p->height, p->width);
+    if (p->row_pitch < p->width || (p->row_pitch % 8))
+        return fail(SVS_ERR_INVALID_ARG, "row_pitch %lld must be >= width and a multiple of 8", (long long)p->row_pitch);
+    if (p->frame_pitch < (int64_t)p->height * p->row_pitch || (p->frame_pitch % 8))
+        return fail(SVS_ERR_INVALID_ARG, "frame_pitch %lld must be >= height*row_pitch and a multiple of 8",
+                    (long long)p->frame_pitch);
+    const uint64_t wb = (uint64_t)p->width / 8, hb = (uint64_t)p->height / 8;
+    const uint64_t bpf = wb * hb, total = bpf * (uint64_t)p->n_frames;
+    if (bpf >= (1ull << 31) || total >= (1ull << 31))
+        return fail(SVS_ERR_INVALID_ARG, "batch has %llu blocks; at most 2^31-1 per call", (unsigned long long)total);
+    g->by_wb = make_div((uint32_t)wb);
+    g->by_bpf = make_div((uint32_t)bpf);
+    g->total_blocks = (uint32_t)total;
+    g->n_ac = (uint32_t)clamp_ac(n_ac);
+    g->row_pitch = p->row_pitch;
+    g->frame_pitch = p->frame_pitch;
+    *total_blocks = total;
+    return SVS_OK;
+}
+
+uint64_t span_bytes(const svs_planes *p) {
+    if (p->n_frames == 0) return 0;
+    return (uint64_t)(p->n_frames - 1) * p->frame_pitch + (uint64_t)(p->height - 1) * p->row_pitch + p->width;
+}
+
+using svs::rows_for;
+
+template <bool DBL>
+int launch_embed(int rows, dim3 grid, hipStream_t st, const uint8_t *gray, uint8_t *stego, const svs::Geometry &g,
+                 const svs::QimParams &qp, const uint32_t *bits, uint64_t bit_offset, uint64_t n_bits,
+                 uint32_t n_words) {
+#define SVS_CASE(R)                                                                                          \
+    case R:                                                                                                  \
+        hipLaunchKernelGGL((svs::embed_kernel<R, DBL>), grid, dim3(256), 0, st, gray, stego, g, qp, bits,    \
+                           bit_offset, n_bits, n_words);                                                     \
+        break;
+    switch (rows) {
+        SVS_CASE(1) SVS_CASE(2) SVS_CASE(3) SVS_CASE(4) SVS_CASE(5) SVS_CASE(6) SVS_CASE(7) SVS_CASE(8)
+        default: return fail(SVS_ERR_INVALID_ARG, "internal: rows=%d", rows);
+    }
+#undef SVS_CASE
+    SVS_HIP(hipGetLastError());
+    return SVS_OK;
+}
+
+int launch_extract(int rows, dim3 grid, hipStream_t st, const uint8_t *gray, const svs::Geometry &g, float delta_f,
+                   uint8_t *out, uint64_t out_bytes) {
+#define SVS_CASE(R)                                                                                             \
+    case R:                                                                                                     \
+        hipLaunchKernelGGL((svs::extract_kernel<R>), grid, dim3(256), 0, st, gray, g, delta_f, out, out_bytes); \
+        break;
+    switch (rows) {
+        SVS_CASE(1) SVS_CASE(2) SVS_CASE(3) SVS_CASE(4) SVS_CASE(5) SVS_CASE(6) SVS_CASE(7) SVS_CASE(8)
+        default: return fail(SVS_ERR_INVALID_ARG, "internal: rows=%d", rows);
+    }
+#undef SVS_CASE
+    SVS_HIP(hipGetLastError());
+    return SVS_OK;
+}
+
+struct DevBuf {  // RAII for the host-pointer entry points
+    void *p = nullptr;
+    ~DevBuf() {
+        if (p) (void)hipFree(p);
+    }
+};
+
+}  // namespace
+
+extern "C" {
+
+int svs_abi_version(void) { return SVS_ABI_VERSION; }
+
+const char *svs_last_error(void) { return g_last_error.c_str(); }
+
+int svs_device_count(int *count) {
+    if (!count) return fail(SVS_ERR_INVALID_ARG, "count is NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        *count = 0;
+        return fail(SVS_ERR_NO_DEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e));
+    }
+    *count = n;
+    return SVS_OK;
+}
+
+int svs_init(int device) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(SVS_ERR_NO_DEVICE, "no HIP device visible");
+    if (device < 0 || device >= n) return fail(SVS_ERR_INVALID_ARG, "device %d out of range (0..%d)", device, n - 1);
+    SVS_HIP(hipSetDevice(device));
+    SVS_HIP(hipFree(nullptr));  // force context creation so later failures are not init failures
+    return SVS_OK;
+}
+
+int svs_device_arch(int device, char *buf, size_t buf_len) {
+    if (!buf || buf_len == 0) return fail(SVS_ERR_INVALID_ARG, "buf is NULL/empty");
+    hipDeviceProp_t prop;
+    SVS_HIP(hipGetDeviceProperties(&prop, device));
+    snprintf(buf, buf_len, "%s", prop.gcnArchName);
+    return SVS_OK;
+}
+
+int svs_malloc(void **dev_ptr, size_t bytes) {
+    if (!dev_ptr) return fail(SVS_ERR_INVALID_ARG, "dev_ptr is NULL");
+    *dev_ptr = nullptr;
+    SVS_HIP(hipMalloc(dev_ptr, bytes ? bytes : 4));
+    return SVS_OK;
+}
+
+int svs_free(void *dev_ptr) {
+    SVS_HIP(hipFree(dev_ptr));
+    return SVS_OK;
+}
+
+int svs_memcpy_h2d(void *dev_dst, const void *host_src, size_t bytes, void *stream) {
+    if (bytes == 0) return SVS_OK;
+    SVS_HIP(hipMemcpyAsync(dev_dst, host_src, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
+    return SVS_OK;
+}
+
+int svs_memcpy_d2h(void *host_dst, const void *dev_src, size_t bytes, void *stream) {
+    if (bytes == 0) return SVS_OK;
+    SVS_HIP(hipMemcpyAsync(host_dst, dev_src, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    return SVS_OK;
+}
+
+int svs_memset(void *dev_dst, int value, size_t bytes, void *stream) {
+    if (bytes == 0) return SVS_OK;
+    SVS_HIP(hipMemsetAsync(dev_dst, value, bytes, (hipStream_t)stream));
+    return SVS_OK;
+}
+
+int svs_stream_synchronize(void *stream) {
+    SVS_HIP(hipStreamSynchronize((hipStream_t)stream));
+    return SVS_OK;
+}
+
+uint64_t svs_capacity_bits(const svs_planes *p, int n_ac) {
+    if (!p || p->n_frames <= 0 || p->height <= 0 || p->width <= 0) return 0;
+    return (uint64_t)p->n_frames * (uint64_t)(p->height / 8) * (uint64_t)(p->width / 8) * (uint64_t)clamp_ac(n_ac);
+}
+
+uint64_t svs_packed_bytes(uint64_t n_bits) { return (n_bits + 7) / 8; }
+
+int svs_embed_dev(const uint8_t *d_gray, uint8_t *d_stego, const svs_planes *planes, double delta, int n_ac,
+                  const uint8_t *d_bits_packed, uint64_t bit_offset, uint64_t n_bits, uint64_t *n_embedded,
+                  void *stream) {
+    svs::Geometry g;
+    uint64_t total = 0;
+    if (int rc = make_geometry(planes, n_ac, &g, &total)) return rc;
+    if (n_embedded) *n_embedded = 0;
+    if (total == 0) return SVS_OK;
+    if (!d_gray || !d_stego) return fail(SVS_ERR_INVALID_ARG, "gray/stego pointer is NULL");
+    if (((uintptr_t)d_gray % 8) || ((uintptr_t)d_stego % 8))
+        return fail(SVS_ERR_INVALID_ARG, "plane pointers must be 8-byte aligned");
+    const int n = (int)g.n_ac;
+    const uint64_t cap = total * (uint64_t)n;
+    uint64_t use = n_bits < cap ? n_bits : cap;
+    if (!(delta > 0.0) || n == 0) use = 0;  // nothing can be embedded (config_and_setup.py:143-145)
+    if (use > 0) {
+        if (!d_bits_packed) return fail(SVS_ERR_INVALID_ARG, "bits pointer is NULL");
+        if ((uintptr_t)d_bits_packed % 4) return fail(SVS_ERR_INVALID_ARG, "bits pointer must be 4-byte aligned");
+        if (bit_offset + use < bit_offset) return fail(SVS_ERR_INVALID_ARG, "bit_offset + n_bits overflows");
+    }
+    const hipStream_t st = (hipStream_t)stream;
+    const dim3 grid((uint32_t)((total + 255) / 256));
+    svs::QimParams qp;
+    qp.delta_f = (float)delta;
+    qp.delta_d = delta;
+    if (use == 0) {
+        // pure copy: every block is "past the budget"
+        if (d_gray == d_stego) return SVS_OK;
+        g.n_ac = 1;
+        qp.delta_f = 1.0f;
+        qp.delta_d = 1.0;
+        return launch_embed<false>(1, grid, st, d_gray, d_stego, g, qp, nullptr, 0, 0, 0);
+    }
+    const uint64_t last_byte = (bit_offset + use + 7) / 8;
+    const uint64_t words = (last_byte + 3) / 4;
+    if (words >= (1ull << 32)) return fail(SVS_ERR_INVALID_ARG, "payload too large for one call");
+    const bool dbl = (double)qp.delta_f != delta;
+    int rc = dbl ? launch_embed<true>(rows_for(n), grid, st, d_gray, d_stego, g, qp,
+                                      reinterpret_cast<const uint32_t *>(d_bits_packed), bit_offset, use, (uint32_t)words)
+                 : launch_embed<false>(rows_for(n), grid, st, d_gray, d_stego, g, qp,
+                                       reinterpret_cast<const uint32_t *>(d_bits_packed), bit_offset, use, (uint32_t)words);
+    if (rc) return rc;
+    if (n_embedded) *n_embedded = use;
+    return SVS_OK;
+}
+
+int svs_extract_dev(const uint8_t *d_gray, const svs_planes *planes, double delta, int n_ac,
+                    uint8_t *d_bits_packed_out, uint64_t out_capacity_bytes, uint64_t *n_bits_out, void *stream) {
+    svs::Geometry g;
+    uint64_t total = 0;
+    if (int rc = make_geometry(planes, n_ac, &g, &total)) return rc;
+    if (n_bits_out) *n_bits_out = 0;
+    const int n = (int)g.n_ac;
+    const uint64_t cap = total * (uint64_t)n;
+    if (cap == 0) return SVS_OK;
+    if (!d_gray || !d_bits_packed_out) return fail(SVS_ERR_INVALID_ARG, "gray/bits pointer is NULL");
+    if ((uintptr_t)d_gray % 8) return fail(SVS_ERR_INVALID_ARG, "plane pointer must be 8-byte aligned");
+    if ((uintptr_t)d_bits_packed_out % 4) return fail(SVS_ERR_INVALID_ARG, "bits pointer must be 4-byte aligned");
+    const uint64_t bytes = (cap + 7) / 8;
+    if (out_capacity_bytes < bytes)
+        return fail(SVS_ERR_CAPACITY, "extract needs %llu bytes, buffer has %llu", (unsigned long long)bytes,
+                    (unsigned long long)out_capacity_bytes);
+    const hipStream_t st = (hipStream_t)stream;
+    if (!(delta > 0.0)) {
+        SVS_HIP(hipMemsetAsync(d_bits_packed_out, 0, bytes, st));  // every bit '0' (config_and_setup.py:143-145)
+    } else {
+        const dim3 grid((uint32_t)((total + 255) / 256));
+        if (int rc = launch_extract(rows_for(n), grid, st, d_gray, g, (float)delta, d_bits_packed_out, bytes)) return rc;
+    }
+    if (n_bits_out) *n_bits_out = cap;
+    return SVS_OK;
+}
+
+int svs_embed(const uint8_t *gray, uint8_t *stego, const svs_planes *planes, double delta, int n_ac,
+              const uint8_t *bits_packed, uint64_t bit_offset, uint64_t n_bits, uint64_t *n_embedded) {
+    svs::Geometry g;
+    uint64_t total = 0;
+    if (int rc = make_geometry(planes, n_ac, &g, &total)) return rc;
+    if (n_embedded) *n_embedded = 0;
+    if (total == 0) return SVS_OK;
+    if (!gray || !stego) return fail(SVS_ERR_INVALID_ARG, "gray/stego pointer is NULL");
+    const uint64_t span = span_bytes(planes);
+    const uint64_t cap = total * (uint64_t)g.n_ac;
+    const uint64_t use = n_bits < cap ? n_bits : cap;
+    if (use && !bits_packed) return fail(SVS_ERR_INVALID_ARG, "bits pointer is NULL");
+    const uint64_t bit_bytes = use ? (bit_offset + use + 7) / 8 : 0;
+    const uint64_t bit_alloc = ((bit_bytes + 3) / 4) * 4 + 4;
+    DevBuf d_frames, d_bits;
+    SVS_HIP(hipMalloc(&d_frames.p, span));
+    SVS_HIP(hipMalloc(&d_bits.p, bit_alloc));
+    SVS_HIP(hipMemcpy(d_frames.p, gray, span, hipMemcpyHostToDevice));
+    SVS_HIP(hipMemset(d_bits.p, 0, bit_alloc));
+    if (bit_bytes) SVS_HIP(hipMemcpy(d_bits.p, bits_packed, bit_bytes, hipMemcpyHostToDevice));
+    uint64_t done = 0;
+    if (int rc = svs_embed_dev((const uint8_t *)d_frames.p, (uint8_t *)d_frames.p, planes, delta, n_ac,
+                               (const uint8_t *)d_bits.p, bit_offset, use, &done, nullptr))
+        return rc;
+    // copy back pixel bytes only (padding in the caller's stego buffer is left alone)
+    if (planes->row_pitch == planes->width && planes->frame_pitch == (int64_t)planes->height * planes->row_pitch) {
+        SVS_HIP(hipMemcpy(stego, d_frames.p, span, hipMemcpyDeviceToHost));
+    } else {
+        for (int f = 0; f < planes->n_frames; ++f)
+            SVS_HIP(hipMemcpy2D(stego + (int64_t)f * planes->frame_pitch, (size_t)planes->row_pitch,
+                                (const uint8_t *)d_frames.p + (int64_t)f * planes->frame_pitch,
+                                (size_t)planes->row_pitch, (size_t)planes->width, (size_t)planes->height,
+                                hipMemcpyDeviceToHost));
+    }
+    SVS_HIP(hipDeviceSynchronize());
+    if (n_embedded) *n_embedded = done;
+    return SVS_OK;
+}
+
+int svs_extract(const uint8_t *gray, const svs_planes *planes, double delta, int n_ac, uint8_t *bits_packed_out,
+                uint64_t out_capacity_bytes, uint64_t *n_bits_out) {
+    svs::Geometry g;
+    uint64_t total = 0;
+    if (int rc = make_geometry(planes, n_ac, &g, &total)) return rc;
+    if (n_bits_out) *n_bits_out = 0;
+    const uint64_t cap = total * (uint64_t)g.n_ac;
+    if (cap == 0) return SVS_OK;
+    if (!gray || !bits_packed_out) return fail(SVS_ERR_INVALID_ARG, "gray/bits pointer is NULL");
+    const uint64_t bytes = (cap + 7) / 8;
+    if (out_capacity_bytes < bytes)
+        return fail(SVS_ERR_CAPACITY, "extract needs %llu bytes, buffer has %llu", (unsigned long long)bytes,
+                    (unsigned long long)out_capacity_bytes);
+    const uint64_t span = span_bytes(planes);
+    DevBuf d_frames, d_bits;
+    SVS_HIP(hipMalloc(&d_frames.p, span));
+    SVS_HIP(hipMalloc(&d_bits.p, bytes + 8));
+    SVS_HIP(hipMemcpy(d_frames.p, gray, span, hipMemcpyHostToDevice));
+    uint64_t got = 0;
+    if (int rc = svs_extract_dev((const uint8_t *)d_frames.p, planes, delta, n_ac, (uint8_t *)d_bits.p, bytes + 8, &got,
+                                 nullptr))
+        return rc;
+    SVS_HIP(hipMemcpy(bits_packed_out, d_bits.p, bytes, hipMemcpyDeviceToHost));
+    SVS_HIP(hipDeviceSynchronize());
+    if (n_bits_out) *n_bits_out = got;
+    return SVS_OK;
+}
+
+int svs_fill_synthetic_dev(uint8_t *d_frames, const svs_planes *planes, uint32_t seed, uint32_t first_frame,
+                           uint32_t lo, uint32_t span, void *stream) {
+    svs::Geometry g;
+    uint64_t total = 0;
+    if (int rc = make_geometry(planes, 1, &g, &total)) return rc;
+    if (total == 0) return SVS_OK;
+    if (!d_frames || ((uintptr_t)d_frames % 8)) return fail(SVS_ERR_INVALID_ARG, "frames pointer NULL or unaligned");
+    if (span == 0 || lo + span > 256) return fail(SVS_ERR_INVALID_ARG, "need span >= 1 and lo + span <= 256");
+    hipLaunchKernelGGL(svs::fill_synthetic_kernel, dim3(4096), dim3(256), 0, (hipStream_t)stream, d_frames,
+                       planes->n_frames, planes->height, planes->width, planes->row_pitch, planes->frame_pitch, seed,
+                       first_frame, lo, span);
+    SVS_HIP(hipGetLastError());
+    return SVS_OK;
+}
+
+int svs_fill_bits_dev(uint8_t *d_bits_packed, uint64_t n_bits, uint32_t seed, uint64_t first_bit, void *stream) {
+    if (n_bits == 0) return SVS_OK;
+    if (!d_bits_packed || ((uintptr_t)d_bits_packed % 4)) return fail(SVS_ERR_INVALID_ARG, "bits pointer NULL or unaligned");
+    const uint64_t words = (n_bits + 31) / 32;
+    const uint32_t blocks = (uint32_t)((words + 255) / 256 < 4096 ? (words + 255) / 256 : 4096);
+    hipLaunchKernelGGL(svs::fill_bits_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<uint32_t *>(d_bits_packed), words, n_bits, seed, first_bit);
+    SVS_HIP(hipGetLastError());
+    return SVS_OK;
+}
+
+int svs_frame_sse_dev(const uint8_t *d_a, const uint8_t *d_b, const svs_planes *planes, uint64_t *d_sse, void *stream) {
+    svs::Geometry g;
+    uint64_t total = 0;
+    if (int rc = make_geometry(planes, 1, &g, &total)) return rc;
+    if (total == 0) return SVS_OK;
+    if (!d_a || !d_b || !d_sse) return fail(SVS_ERR_INVALID_ARG, "NULL pointer");
+    if (((uintptr_t)d_a % 8) || ((uintptr_t)d_b % 8) || ((uintptr_t)d_sse % 8))
+        return fail(SVS_ERR_INVALID_ARG, "pointers must be 8-byte aligned");
+    if (planes->n_frames > 65535) return fail(SVS_ERR_INVALID_ARG, "at most 65535 frames per call");
+    const hipStream_t st = (hipStream_t)stream;
+    SVS_HIP(hipMemsetAsync(d_sse, 0, sizeof(uint64_t) * (size_t)planes->n_frames, st));
+    hipLaunchKernelGGL(svs::frame_sse_kernel, dim3(64, (uint32_t)planes->n_frames), dim3(256), 0, st, d_a, d_b,
+                       planes->height, planes->width, planes->row_pitch, planes->frame_pitch,
+                       reinterpret_cast<unsigned long long *>(d_sse));
+    SVS_HIP(hipGetLastError());
+    return SVS_OK;
+}
+
+int svs_bit_errors_dev(const uint8_t *d_a_packed, const uint8_t *d_b_packed, uint64_t n_bits, uint64_t *d_count,
+                       void *stream) {
+    if (!d_count || ((uintptr_t)d_count % 8)) return fail(SVS_ERR_INVALID_ARG, "count pointer NULL or unaligned");
+    const hipStream_t st = (hipStream_t)stream;
+    SVS_HIP(hipMemsetAsync(d_count, 0, sizeof(uint64_t), st));
+    if (n_bits == 0) return SVS_OK;
+    if (!d_a_packed || !d_b_packed) return fail(SVS_ERR_INVALID_ARG, "NULL pointer");
+    const uint64_t bytes = (n_bits + 7) / 8;
+    const uint32_t blocks = (uint32_t)((bytes + 255) / 256 < 2048 ? (bytes + 255) / 256 : 2048);
+    hipLaunchKernelGGL(svs::bit_errors_kernel, dim3(blocks), dim3(256), 0, st, d_a_packed, d_b_packed, n_bits,
+                       reinterpret_cast<unsigned long long *>(d_count));
+    SVS_HIP(hipGetLastError());
+    return SVS_OK;
+}
+
+// test hook (not part of the product ABI): what v_cvt_pk_u8_f32 does on this device
+int svs_probe_cvt_pk_u8(const float *host_in, uint32_t *host_out, int n) {
+    if (n <= 0) return SVS_OK;
+    DevBuf a, b;
+    SVS_HIP(hipMalloc(&a.p, sizeof(float) * n));
+    SVS_HIP(hipMalloc(&b.p, sizeof(uint32_t) * n));
+    SVS_HIP(hipMemcpy(a.p, host_in, sizeof(float) * n, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(svs::probe_cvt_pk_u8_kernel, dim3((n + 63) / 64), dim3(64), 0, nullptr, (const float *)a.p,
+                       (uint32_t *)b.p, n);
+    SVS_HIP(hipGetLastError());
+    SVS_HIP(hipMemcpy(host_out, b.p, sizeof(uint32_t) * n, hipMemcpyDeviceToHost));
+    return SVS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,239 @@
+// svs_device.hpp - gfx950 kernels of the fused block-DCT / QIM frame operator.
+// Per-block arithmetic lives in svs_block.hpp; this file maps blocks to lanes, moves bytes
+// between HBM and registers, and packs the extracted bit stream.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "svs_block.hpp"
+
+namespace svs {
+
+// ---------------------------------------------------------------------------------------
+// geometry shared by all kernels; division by W/8 and by blocks-per-frame is done with
+// host-computed multipliers (exact for dividends < 2^31)
+// ---------------------------------------------------------------------------------------
+struct FastDiv {
+    uint32_t mul;
+    uint32_t shift;  // 31..62
+    uint32_t div;
+    uint32_t pad;
+};
+
+struct Geometry {
+    FastDiv by_wb;          // divide by blocks per block-row
+    FastDiv by_bpf;         // divide by blocks per frame
+    uint32_t total_blocks;  // n_frames * blocks per frame   (< 2^31)
+    uint32_t n_ac;          // 1..63
+    int64_t row_pitch;
+    int64_t frame_pitch;
+};
+
+__device__ __forceinline__ uint32_t fast_div(uint32_t n, const FastDiv &d) {
+    return (uint32_t)(((uint64_t)n * d.mul) >> d.shift);
+}
+
+// byte offset of the top-left pixel of global block `gblock` (frames in order, raster inside)
+__device__ __forceinline__ int64_t block_offset(uint32_t gblock, const Geometry &g) {
+    const uint32_t frame = fast_div(gblock, g.by_bpf);
+    const uint32_t in_frame = gblock - frame * g.by_bpf.div;
+    const uint32_t brow = fast_div(in_frame, g.by_wb);
+    const uint32_t bcol = in_frame - brow * g.by_wb.div;
+    return (int64_t)frame * g.frame_pitch + (int64_t)(brow * 8u) * g.row_pitch + (int64_t)(bcol * 8u);
+}
+
+__device__ __forceinline__ void load_block(const uint8_t *src, int64_t row_pitch, Row8 (&raw)[8]) {
+#pragma unroll
+    for (int y = 0; y < 8; ++y) raw[y] = *reinterpret_cast<const Row8 *>(src + y * row_pitch);
+}
+
+__device__ __forceinline__ void store_block(uint8_t *dst, int64_t row_pitch, const Row8 (&raw)[8]) {
+#pragma unroll
+    for (int y = 0; y < 8; ++y) *reinterpret_cast<Row8 *>(dst + y * row_pitch) = raw[y];
+}
+
+// ---------------------------------------------------------------------------------------
+// EMBED: one lane = one block.  grid = ceil(total_blocks / 256) workgroups of 256.
+// HBM traffic per block: 64 B read + 64 B written + n payload bits read.
+// ---------------------------------------------------------------------------------------
+template <int U, bool DBL>
+__global__ __launch_bounds__(256) void embed_kernel(const uint8_t *__restrict__ gray,
+                                                    uint8_t *__restrict__ stego, const Geometry g,
+                                                    const QimParams qp,
+                                                    const uint32_t *__restrict__ bits,
+                                                    const uint64_t bit_offset, const uint64_t n_bits,
+                                                    const uint32_t n_words) {
+    const uint32_t gblock = blockIdx.x * 256u + threadIdx.x;
+    if (gblock >= g.total_blocks) return;
+    const int64_t off = block_offset(gblock, g);
+
+    Row8 raw[8];
+    load_block(gray + off, g.row_pitch, raw);
+
+    const uint32_t n = g.n_ac;
+    const uint64_t first = (uint64_t)gblock * n;  // stream index of this block's first bit
+    const uint32_t nb = block_budget(first, n_bits, n);
+    if (nb == 0) {
+        // past the budget: byte-identical copy (the reference's loops `break`, :130,:132)
+        if (stego != gray) store_block(stego + off, g.row_pitch, raw);
+        return;
+    }
+    uint32_t hi, lo;
+    payload_window(bits, n_words, bit_offset + first, hi, lo);
+    embed_block<U, DBL>(raw, n, nb, hi, lo, qp);
+    store_block(stego + off, g.row_pitch, raw);
+}
+
+// ---------------------------------------------------------------------------------------
+// EXTRACT: one lane = one block; a wavefront's 64 blocks produce exactly n aligned 64-bit words
+// of the packed stream (stream bit = global block * n + i), assembled through a wave-private LDS
+// byte array and written with plain dword stores - no atomics, no pre-zeroed output.
+// HBM traffic per block: 64 B read + n bits written.
+// ---------------------------------------------------------------------------------------
+template <int U>
+__global__ __launch_bounds__(256) void extract_kernel(const uint8_t *__restrict__ gray, const Geometry g,
+                                                      const float delta_f, uint8_t *__restrict__ out,
+                                                      const uint64_t out_bytes) {
+    __shared__ __attribute__((aligned(16))) uint8_t flags[4][64 * 64];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t gblock = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t n = g.n_ac;
+
+    uint32_t hi = 0, lo = 0;  // this block's bits, MSB first: bit i at position 63-i of hi:lo
+    if (gblock < g.total_blocks) {
+        Row8 raw[8];
+        load_block(gray + block_offset(gblock, g), g.row_pitch, raw);
+        extract_block<U>(raw, n, delta_f, hi, lo);
+    }
+
+    // lane writes its n flag bytes at [lane*n, lane*n + n)
+    uint8_t *mine = &flags[wave][0];
+#pragma unroll
+    for (int i = 0; i < 8 * U - 1; ++i) {
+        if ((uint32_t)i < n) mine[lane * n + i] = (uint8_t)window_bit(hi, lo, i);
+    }
+    __syncthreads();
+
+    // 64*n flag bytes -> 2n dwords of packed stream; dword w of this wave covers flags [32w, 32w+32)
+    const uint64_t wave_first_block = (uint64_t)blockIdx.x * 256u + wave * 64u;
+    const uint64_t wave_byte0 = wave_first_block * n / 8u;  // 64*n bits per wave -> multiple of 8 bytes
+    for (uint32_t w = lane; w < 2u * n; w += 64u) {
+        const uint4 f0 = *reinterpret_cast<const uint4 *>(mine + 32u * w);
+        const uint4 f1 = *reinterpret_cast<const uint4 *>(mine + 32u * w + 16u);
+        // four 0/1 bytes (first flag in the low byte) -> nibble with the first flag as MSB
+#define SVS_NIB(X) ((((X) * 0x08040201u) >> 24) & 0xFu)
+        const uint32_t b0 = (SVS_NIB(f0.x) << 4) | SVS_NIB(f0.y);
+        const uint32_t b1 = (SVS_NIB(f0.z) << 4) | SVS_NIB(f0.w);
+        const uint32_t b2 = (SVS_NIB(f1.x) << 4) | SVS_NIB(f1.y);
+        const uint32_t b3 = (SVS_NIB(f1.z) << 4) | SVS_NIB(f1.w);
+#undef SVS_NIB
+        const uint32_t word = b0 | (b1 << 8) | (b2 << 16) | (b3 << 24);
+        const uint64_t at = wave_byte0 + 4ull * w;
+        if (at + 4 <= out_bytes) {
+            *reinterpret_cast<uint32_t *>(out + at) = word;
+        } else {
+            for (uint32_t j = 0; j < 4 && at + j < out_bytes; ++j) out[at + j] = (uint8_t)(word >> (8 * j));
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// measurement helpers
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t lowbias32(uint32_t h) {
+    h ^= h >> 16; h *= 0x7FEB352Du; h ^= h >> 15; h *= 0x846CA68Bu; h ^= h >> 16;
+    return h;
+}
+
+// 8 pixels per thread per step; same hash as svsdct/synth.py
+__global__ __launch_bounds__(256) void fill_synthetic_kernel(uint8_t *__restrict__ frames, int32_t n_frames,
+                                                             int32_t height, int32_t width, int64_t row_pitch,
+                                                             int64_t frame_pitch, uint32_t seed,
+                                                             uint32_t first_frame, uint32_t lo, uint32_t span) {
+    const uint32_t groups_per_row = (uint32_t)width / 8u;
+    const uint64_t total = (uint64_t)n_frames * height * groups_per_row;
+    for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+         t += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t xg = (uint32_t)(t % groups_per_row);
+        const uint64_t r = t / groups_per_row;
+        const uint32_t y = (uint32_t)(r % (uint32_t)height), f = (uint32_t)(r / (uint32_t)height);
+        const uint32_t base = seed + (f + first_frame) * 0x9E3779B1u + y * 0x85EBCA6Bu;
+        uint32_t px[2] = {0, 0};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const uint32_t x = xg * 8u + j;
+            const uint32_t v = lo + lowbias32(base + x * 0xC2B2AE35u) % span;
+            px[j >> 2] |= v << (8 * (j & 3));
+        }
+        Row8 r8;
+        r8.x = px[0];
+        r8.y = px[1];
+        *reinterpret_cast<Row8 *>(frames + (int64_t)f * frame_pitch + (int64_t)y * row_pitch + xg * 8u) = r8;
+    }
+}
+
+__global__ __launch_bounds__(256) void fill_bits_kernel(uint32_t *__restrict__ words, uint64_t n_words,
+                                                        uint64_t n_bits, uint32_t seed, uint64_t first_bit) {
+    const uint32_t s = seed * 0x632BE5ABu;
+    for (uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; w < n_words;
+         w += (uint64_t)gridDim.x * blockDim.x) {
+        uint32_t be = 0;  // big-endian view: stream bit 32w+j at bit 31-j
+        for (uint32_t j = 0; j < 32; ++j) {
+            const uint64_t i = 32ull * w + j;
+            if (i < n_bits) be |= (lowbias32(s + (uint32_t)(first_bit + i)) >> 31) << (31 - j);
+        }
+        words[w] = __builtin_bswap32(be);
+    }
+}
+
+// per-frame sum of squared differences; blockIdx.y = frame, 8 pixels per thread per step,
+// partial sums reduced in-wave, one 64-bit atomic per wave
+__global__ __launch_bounds__(256) void frame_sse_kernel(const uint8_t *__restrict__ a, const uint8_t *__restrict__ b,
+                                                        int32_t height, int32_t width, int64_t row_pitch,
+                                                        int64_t frame_pitch, unsigned long long *__restrict__ sse) {
+    const uint32_t f = blockIdx.y;
+    const uint32_t groups_per_row = (uint32_t)width / 8u;
+    const uint64_t total = (uint64_t)height * groups_per_row;
+    unsigned long long acc = 0;
+    for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+         t += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t xg = (uint32_t)(t % groups_per_row), y = (uint32_t)(t / groups_per_row);
+        const int64_t off = (int64_t)f * frame_pitch + (int64_t)y * row_pitch + xg * 8u;
+        const Row8 va = *reinterpret_cast<const Row8 *>(a + off);
+        const Row8 vb = *reinterpret_cast<const Row8 *>(b + off);
+        const uint32_t wa[2] = {va.x, va.y}, wb[2] = {vb.x, vb.y};
+        uint32_t s = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int d = (int)((wa[j >> 2] >> (8 * (j & 3))) & 0xff) - (int)((wb[j >> 2] >> (8 * (j & 3))) & 0xff);
+            s += (uint32_t)(d * d);
+        }
+        acc += s;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+    if ((threadIdx.x & 63u) == 0 && acc) atomicAdd(&sse[f], acc);
+}
+
+__global__ __launch_bounds__(256) void bit_errors_kernel(const uint8_t *__restrict__ a, const uint8_t *__restrict__ b,
+                                                         uint64_t n_bits, unsigned long long *__restrict__ count) {
+    const uint64_t n_bytes = (n_bits + 7) / 8;
+    unsigned long long acc = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_bytes;
+         i += (uint64_t)gridDim.x * blockDim.x) {
+        uint32_t x = (uint32_t)(a[i] ^ b[i]);
+        if (i == n_bytes - 1 && (n_bits & 7u)) x &= 0xFFu << (8 - (n_bits & 7u));
+        acc += __popc(x);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+    if ((threadIdx.x & 63u) == 0 && acc) atomicAdd(count, acc);
+}
+
+// probe used by tests/test_gpu_primitives.py: what v_cvt_pk_u8_f32 does with a value
+__global__ void probe_cvt_pk_u8_kernel(const float *__restrict__ in, uint32_t *__restrict__ out, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = __builtin_amdgcn_cvt_pk_u8_f32(in[i], 0, 0u);
+}
+
+}  // namespace svs

@@ -1,0 +1,146 @@
+"""Batched embed / extract over stacks of gray frames - the frame loops of the reference
+(embed_process.py:108-128, extract_process.py:55-86,173-182) turned into one kernel launch per
+batch.  Frame k of a batch takes stream bits [k*cap, (k+1)*cap) (cap = blocks per frame * n_ac);
+the extracted stream is the frames' bits in order.
+
+Two levels:
+  * `embed_frames` / `extract_frames`      NumPy in, NumPy out (host entry points of the C ABI).
+  * `embed_device` / `extract_device`      raw device pointers + stream (what bench.py and a
+                                           device-resident pipeline use); nothing is copied.
+Bits travel packed MSB-first (numpy.packbits order), so `unpack_to_str` of the extract output is
+the reference operator's '0'/'1' string.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import native
+from .native import Planes
+
+MAX_AC = 63
+
+
+def clamp_ac(n_ac) -> int:
+    return max(0, min(int(n_ac), MAX_AC))  # config_and_setup.py:138
+
+
+def capacity_bits(n_frames: int, height: int, width: int, n_ac) -> int:
+    return n_frames * (height // 8) * (width // 8) * clamp_ac(n_ac)
+
+
+# ---- payload forms --------------------------------------------------------------------------
+def str_to_bits(payload: str, limit: int | None = None) -> np.ndarray:
+    """'0101...' -> uint8 0/1 array (vectorised; only the first `limit` characters are touched)."""
+    if limit is not None:
+        payload = payload[:limit]
+    return np.frombuffer(payload.encode("ascii"), np.uint8) - np.uint8(48)
+
+
+def bits_to_str(bits: np.ndarray) -> str:
+    return (np.asarray(bits, np.uint8) + np.uint8(48)).tobytes().decode("ascii")
+
+
+def pack_bits(bits: np.ndarray) -> np.ndarray:
+    """0/1 array -> MSB-first packed bytes, zero padded to a multiple of 4 bytes (the C ABI reads
+    the payload as aligned dwords)."""
+    packed = np.packbits(np.asarray(bits, np.uint8))
+    pad = (-packed.size) % 4
+    if pad or packed.size == 0:
+        packed = np.concatenate([packed, np.zeros(pad if packed.size else 4, np.uint8)])
+    return packed
+
+
+def unpack_to_str(packed: np.ndarray, n_bits: int) -> str:
+    return bits_to_str(np.unpackbits(np.asarray(packed, np.uint8), count=n_bits))
+
+
+# ---- host-array level -----------------------------------------------------------------------
+def _as_stack(frames: np.ndarray) -> np.ndarray:
+    a = np.asarray(frames)
+    if a.dtype != np.uint8:
+        raise TypeError("frames must be uint8")
+    if a.ndim == 2:
+        a = a[None]
+    if a.ndim != 3:
+        raise ValueError("frames must be [H,W] or [F,H,W] gray planes")
+    if a.shape[1] % 8 or a.shape[2] % 8:
+        raise ValueError("frame height and width must be multiples of 8")
+    return np.ascontiguousarray(a)
+
+
+def embed_frames(frames: np.ndarray, delta, n_ac, bits, bit_offset: int = 0, n_bits: int | None = None,
+                 device: int = 0):
+    """Embed a bit stream into a stack of gray frames on the GPU.
+
+    frames : uint8 [F,H,W] (or [H,W]);  bits : 0/1 array or '0'/'1' str (the stream; bit
+    `bit_offset` is the first one used);  n_bits : bits available from bit_offset (default: rest).
+    Returns (stego uint8 [F,H,W], n_embedded)."""
+    lib = native.load()
+    native.ensure_device(device)
+    stack = _as_stack(frames)
+    f, h, w = stack.shape
+    if isinstance(bits, str):
+        bits = str_to_bits(bits)
+    bits = np.asarray(bits, np.uint8)
+    if n_bits is None:
+        n_bits = max(0, bits.size - bit_offset)
+    if bit_offset + n_bits > bits.size:
+        raise ValueError("bit_offset + n_bits exceeds the payload length")
+    packed = pack_bits(bits)
+    stego = np.empty_like(stack)
+    done = C.c_uint64(0)
+    planes = Planes.contiguous(f, h, w)
+    rc = lib.svs_embed(stack.ctypes.data, stego.ctypes.data, C.byref(planes), float(delta), int(n_ac),
+                       packed.ctypes.data, int(bit_offset), int(n_bits), C.byref(done))
+    native.check(rc, "svs_embed")
+    return stego, int(done.value)
+
+
+def extract_frames(frames: np.ndarray, delta, n_ac, device: int = 0):
+    """Extract the packed bit stream of a stack of gray frames on the GPU.
+    Returns (packed uint8 [ceil(n_bits/8)], n_bits)."""
+    lib = native.load()
+    native.ensure_device(device)
+    stack = _as_stack(frames)
+    f, h, w = stack.shape
+    cap = capacity_bits(f, h, w, n_ac)
+    out = np.zeros(max(4, (cap + 7) // 8 + (-((cap + 7) // 8)) % 4), np.uint8)
+    got = C.c_uint64(0)
+    planes = Planes.contiguous(f, h, w)
+    rc = lib.svs_extract(stack.ctypes.data, C.byref(planes), float(delta), int(n_ac), out.ctypes.data,
+                         out.size, C.byref(got))
+    native.check(rc, "svs_extract")
+    n = int(got.value)
+    return out[: (n + 7) // 8], n
+
+
+# ---- device-pointer level -------------------------------------------------------------------
+def embed_device(d_gray: int, d_stego: int, planes: Planes, delta, n_ac, d_bits_packed: int,
+                 bit_offset: int, n_bits: int, stream: int = 0) -> int:
+    """Enqueue the embed kernel on `stream` (a hipStream_t handle as int); returns bits embedded."""
+    done = C.c_uint64(0)
+    rc = native.load().svs_embed_dev(d_gray, d_stego, C.byref(planes), float(delta), int(n_ac), d_bits_packed,
+                                     int(bit_offset), int(n_bits), C.byref(done), stream or None)
+    native.check(rc, "svs_embed_dev")
+    return int(done.value)
+
+
+def extract_device(d_gray: int, planes: Planes, delta, n_ac, d_bits_out: int, out_capacity_bytes: int,
+                   stream: int = 0) -> int:
+    """Enqueue the extract kernel on `stream`; returns the number of bits the batch yields."""
+    got = C.c_uint64(0)
+    rc = native.load().svs_extract_dev(d_gray, C.byref(planes), float(delta), int(n_ac), d_bits_out,
+                                       int(out_capacity_bytes), C.byref(got), stream or None)
+    native.check(rc, "svs_extract_dev")
+    return int(got.value)
+
+
+# ---- frame sharding across ranks ----------------------------------------------
+def shard_frames(n_frames: int, world_size: int, rank: int) -> tuple[int, int]:
+    """Contiguous frame range [first, first+count) of `rank`, so that the global bit stream is the
+    rank-order concatenation of the ranks' streams."""
+    base, extra = divmod(n_frames, world_size)
+    first = rank * base + min(rank, extra)
+    return first, base + (1 if rank < extra else 0)

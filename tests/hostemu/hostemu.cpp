@@ -1,0 +1,119 @@
+// hostemu.cpp - TEST INFRASTRUCTURE ONLY (never loaded by the product package).
+//
+// Runs csrc/svs_block.hpp - the exact per-block arithmetic and bit bookkeeping the gfx950 kernels
+// execute - on the CPU, block by block, so that the CPU-only test tier (and ASan/UBSan) can check
+// it against the oracle without a GPU.  The lane/wave mapping, HBM access and LDS bit packing of
+// the kernels are NOT modelled here; those are covered by the -m gpu tests.
+// Build: g++ -O2 -ffp-contract=off -std=c++17 -shared -fPIC -I<csrc> hostemu.cpp -o libsvs_hostemu.so
+#include <cstdint>
+#include <cstring>
+
+#include "svs_block.hpp"
+
+namespace {
+
+template <int U>
+void embed_u(svs::Row8 (&raw)[8], uint32_t n, uint32_t nb, uint32_t hi, uint32_t lo, const svs::QimParams &qp, bool dbl) {
+    if (dbl) svs::embed_block<U, true>(raw, n, nb, hi, lo, qp);
+    else svs::embed_block<U, false>(raw, n, nb, hi, lo, qp);
+}
+
+void embed_dispatch(int rows, svs::Row8 (&raw)[8], uint32_t n, uint32_t nb, uint32_t hi, uint32_t lo,
+                    const svs::QimParams &qp, bool dbl) {
+    switch (rows) {
+        case 1: embed_u<1>(raw, n, nb, hi, lo, qp, dbl); break;
+        case 2: embed_u<2>(raw, n, nb, hi, lo, qp, dbl); break;
+        case 3: embed_u<3>(raw, n, nb, hi, lo, qp, dbl); break;
+        case 4: embed_u<4>(raw, n, nb, hi, lo, qp, dbl); break;
+        case 5: embed_u<5>(raw, n, nb, hi, lo, qp, dbl); break;
+        case 6: embed_u<6>(raw, n, nb, hi, lo, qp, dbl); break;
+        case 7: embed_u<7>(raw, n, nb, hi, lo, qp, dbl); break;
+        default: embed_u<8>(raw, n, nb, hi, lo, qp, dbl); break;
+    }
+}
+
+void extract_dispatch(int rows, const svs::Row8 (&raw)[8], uint32_t n, float d, uint32_t &hi, uint32_t &lo) {
+    switch (rows) {
+        case 1: svs::extract_block<1>(raw, n, d, hi, lo); break;
+        case 2: svs::extract_block<2>(raw, n, d, hi, lo); break;
+        case 3: svs::extract_block<3>(raw, n, d, hi, lo); break;
+        case 4: svs::extract_block<4>(raw, n, d, hi, lo); break;
+        case 5: svs::extract_block<5>(raw, n, d, hi, lo); break;
+        case 6: svs::extract_block<6>(raw, n, d, hi, lo); break;
+        case 7: svs::extract_block<7>(raw, n, d, hi, lo); break;
+        default: svs::extract_block<8>(raw, n, d, hi, lo); break;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+// frames: contiguous [F][H][W]; bits: packed MSB-first, padded by the caller to a multiple of 4 bytes
+uint64_t emu_embed(const uint8_t *gray, uint8_t *stego, int F, int H, int W, double delta, int n_ac,
+                   const uint8_t *bits, uint64_t bits_bytes, uint64_t bit_offset, uint64_t n_bits) {
+    const int n = n_ac < 0 ? 0 : (n_ac > 63 ? 63 : n_ac);
+    const uint64_t bpf = (uint64_t)(H / 8) * (W / 8), total = bpf * F;
+    std::memcpy(stego, gray, (size_t)F * H * W);
+    uint64_t use = n_bits < total * n ? n_bits : total * n;
+    if (!(delta > 0.0) || n == 0) use = 0;
+    if (use == 0) return 0;
+    svs::QimParams qp{(float)delta, delta};
+    const bool dbl = (double)qp.delta_f != delta;
+    const uint32_t n_words = (uint32_t)(bits_bytes / 4);
+    for (uint64_t gb = 0; gb < total; ++gb) {
+        const uint64_t first = gb * n;
+        const uint32_t nb = svs::block_budget(first, use, (uint32_t)n);
+        if (nb == 0) break;
+        const uint64_t f = gb / bpf, b = gb % bpf;
+        const uint64_t by = b / (W / 8), bx = b % (W / 8);
+        uint8_t *p = stego + f * (uint64_t)H * W + by * 8 * W + bx * 8;
+        svs::Row8 raw[8];
+        for (int y = 0; y < 8; ++y) std::memcpy(&raw[y], p + (size_t)y * W, 8);
+        uint32_t hi, lo;
+        svs::payload_window(reinterpret_cast<const uint32_t *>(bits), n_words, bit_offset + first, hi, lo);
+        embed_dispatch(svs::rows_for(n), raw, (uint32_t)n, nb, hi, lo, qp, dbl);
+        for (int y = 0; y < 8; ++y) std::memcpy(p + (size_t)y * W, &raw[y], 8);
+    }
+    return use;
+}
+
+// out_flags: one byte (0/1) per extracted bit, F*(H/8)*(W/8)*n entries
+uint64_t emu_extract(const uint8_t *gray, int F, int H, int W, double delta, int n_ac, uint8_t *out_flags) {
+    const int n = n_ac < 0 ? 0 : (n_ac > 63 ? 63 : n_ac);
+    const uint64_t bpf = (uint64_t)(H / 8) * (W / 8), total = bpf * F;
+    if (n == 0) return 0;
+    if (!(delta > 0.0)) {
+        std::memset(out_flags, 0, total * n);
+        return total * n;
+    }
+    for (uint64_t gb = 0; gb < total; ++gb) {
+        const uint64_t f = gb / bpf, b = gb % bpf;
+        const uint64_t by = b / (W / 8), bx = b % (W / 8);
+        const uint8_t *p = gray + f * (uint64_t)H * W + by * 8 * W + bx * 8;
+        svs::Row8 raw[8];
+        for (int y = 0; y < 8; ++y) std::memcpy(&raw[y], p + (size_t)y * W, 8);
+        uint32_t hi, lo;
+        extract_dispatch(svs::rows_for(n), raw, (uint32_t)n, (float)delta, hi, lo);
+        for (int i = 0; i < n; ++i) out_flags[gb * n + i] = (uint8_t)svs::window_bit(hi, lo, i);
+    }
+    return total * n;
+}
+
+// forward coefficients of one block (for the DCT accuracy test): D[8][8]
+void emu_forward_block(const uint8_t *block64, float *D64) {
+    svs::Row8 raw[8];
+    for (int y = 0; y < 8; ++y) std::memcpy(&raw[y], block64 + 8 * y, 8);
+    float D[8][8];
+    svs::forward_rows<8>(raw, D);
+    std::memcpy(D64, D, sizeof D);
+}
+
+void emu_idct8(const float *X, float *x) {
+    float a[8], b[8];
+    std::memcpy(a, X, sizeof a);
+    svs::idct8<8, false>(a, b);
+    std::memcpy(x, b, sizeof b);
+}
+
+}  // extern "C"

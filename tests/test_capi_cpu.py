@@ -1,0 +1,95 @@
+"""CPU tier: the C-ABI library loads without a GPU and exports every symbol include/svsdct.h
+declares; host-side logic of the package (no compute calls)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from helpers import REPO
+from svsdct import batch, native, synth
+
+
+def _declared_symbols():
+    text = open(os.path.join(REPO, "include", "svsdct.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(svs_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    names = _declared_symbols()
+    assert len(names) >= 20
+    lib = native.load()
+    for name in names:
+        assert hasattr(lib, name), name
+    assert sorted(native.SIGNATURES) == names          # the binding covers the header, nothing more
+    assert lib.svs_abi_version() == 1
+
+
+def test_capacity_arithmetic_without_gpu():
+    lib = native.load()
+    p = native.Planes.contiguous(600, 2160, 3840)
+    assert lib.svs_capacity_bits(C.byref(p), 3) == 600 * 129600 * 3 == batch.capacity_bits(600, 2160, 3840, 3)
+    assert lib.svs_capacity_bits(C.byref(p), 100) == 600 * 129600 * 63       # clamp (config_and_setup.py:138)
+    assert lib.svs_capacity_bits(C.byref(p), -4) == 0
+    assert lib.svs_packed_bytes(9) == 2
+
+
+def test_product_path_has_no_cpu_fallback(monkeypatch):
+    """Without a GPU the operator must fail loudly, not compute on the CPU."""
+    if os.path.exists("/dev/kfd"):
+        pytest.skip("a GPU is present")
+    import config_and_setup as cs
+    with pytest.raises(native.SvsNativeError):
+        cs.proses_frame_qim_dct(np.zeros((16, 16), np.uint8), "extract", 8, num_ac_coeffs_to_use=3)
+    monkeypatch.setattr(native, "_lib", None)
+    monkeypatch.setattr(native, "LIB_PATH", "/nonexistent/libsvsdct.so")
+    with pytest.raises(native.SvsNativeError, match="no CPU fallback"):
+        native.load()
+
+
+def test_product_package_never_imports_the_oracle():
+    pkg = os.path.join(REPO, "secure-video-steganography-using-ecc-and-dct_amd")
+    for root, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h")):
+                text = open(os.path.join(root, f)).read()
+                assert "import oracle" not in text and "from oracle" not in text and "hostemu" not in text.replace(
+                    "tests/hostemu", ""), os.path.join(root, f)
+
+
+def test_bit_string_forms():
+    import config_and_setup as cs
+    assert cs.bytes_ke_bitstream(b"\x80\x01\xff") == "100000000000000111111111"
+    assert cs.bitstream_ke_bytes("1000000000000001") == b"\x80\x01"
+    assert cs.bitstream_ke_bytes("10000000" + "101") == b"\x80"          # trailing partial byte dropped
+    with pytest.raises(ValueError, match="kosong"):
+        cs.bitstream_ke_bytes("101")
+    assert cs.int_ke_bitstream(5, 8) == "00000101"
+    with pytest.raises(ValueError):
+        cs.int_ke_bitstream(256, 8)
+    assert cs.bitstream_ke_int("00000101", 8) == 5
+    with pytest.raises(ValueError):
+        cs.bitstream_ke_int("101", 8)
+    with pytest.raises(ValueError):
+        cs.bitstream_ke_int("")
+    bits = synth.synthetic_bits(77)
+    assert np.array_equal(batch.str_to_bits(batch.bits_to_str(bits)), bits)
+    assert batch.unpack_to_str(batch.pack_bits(bits), 77) == batch.bits_to_str(bits)
+    assert batch.pack_bits(bits).size % 4 == 0
+    assert batch.str_to_bits("1" * 100, 7).size == 7
+
+
+def test_frame_sharding_covers_everything_in_order():
+    for n, world in [(600, 8), (7, 3), (3, 8), (0, 2)]:
+        spans = [batch.shard_frames(n, world, r) for r in range(world)]
+        assert spans[0][0] == 0 and sum(c for _, c in spans) == n
+        for (a, ca), (b, _) in zip(spans, spans[1:]):
+            assert a + ca == b
+
+
+def test_operator_rejects_bad_rank_before_touching_the_gpu():
+    import config_and_setup as cs
+    with pytest.raises(ValueError, match="Format frame input tidak didukung."):
+        cs.proses_frame_qim_dct(np.zeros((8, 8, 4), np.uint8), "extract", 8)

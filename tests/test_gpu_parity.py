@@ -1,0 +1,289 @@
+"""GPU tier (-m gpu): the HIP kernels, called through the C ABI (libsvsdct.so), against the
+pinned oracle, the reference's golden vectors and size-independent properties at BASELINE sizes.
+
+Parity bar (BASELINE.json north_star): extracted payload bits bit-exact; stego-frame PSNR within
++-0.01 dB of the reference's.  Stego PIXELS are not required to be identical (exact
+rounding ties resolve by pocketfft's float32 noise) - the number that differ is written to
+gpurun_out/parity_report.json for the record.
+"""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+from helpers import (NOISE_ONLY_CASES, REPO, case_inputs, emu_embed, emu_extract, exact_tie_mask, golden_bits,
+                     single_frame_cases)
+from oracle import qim_dct_oracle as orc
+from svsdct import batch, native, synth
+from svsdct.native import Planes
+
+pytestmark = pytest.mark.gpu
+PSNR_TOL_DB = 0.01
+_REPORT = {}
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _device():
+    native.ensure_device(0)
+    yield
+    out = os.path.join(REPO, "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, "parity_report.json"), "w") as fh:
+        json.dump(_REPORT, fh, indent=1, sort_keys=True)
+
+
+def test_device_is_gfx950():
+    assert native.device_arch(0).startswith("gfx950")
+
+
+def test_golden_vectors(golden):
+    arrays, meta = golden
+    for name in single_frame_cases(meta):
+        info, gray, payload = case_inputs(arrays, meta, name)
+        delta, n_ac = info["delta"], info["n_ac"]
+        stego, used = batch.embed_frames(gray, delta, n_ac, payload)
+        stego = stego[0]
+        _, ref_stego, ref_used = orc.frame_embed(gray, delta, payload, n_ac)
+
+        # (a) extraction from the REFERENCE's stego frame is bit-exact
+        packed, n_bits = batch.extract_frames(ref_stego, delta, n_ac)
+        assert n_bits == info["ext_stego_len"], name
+        assert np.array_equal(np.unpackbits(packed, count=n_bits),
+                              golden_bits(arrays, name, "ext_stego", n_bits)), name
+        # (b) extraction from our own stego frame agrees with the oracle on the same frame
+        packed, n_bits = batch.extract_frames(stego, delta, n_ac)
+        own = np.unpackbits(packed, count=n_bits)
+        assert np.array_equal(own, orc.frame_extract_bits(stego, delta, n_ac)), name
+        # the kernels compute exactly what the CPU build of the same header computes
+        emu_stego, emu_used = emu_embed(gray, delta, n_ac, payload)
+        assert emu_used == used and np.array_equal(emu_stego[0], stego), name
+
+        _REPORT[name] = {"pixels": int(gray.size), "pixels_differing_from_reference": int((stego != ref_stego).sum()),
+                         "psnr": orc.psnr_u8(gray, stego), "psnr_reference": info["psnr"]}
+        if name in NOISE_ONLY_CASES:
+            assert np.array_equal(stego, gray), name
+            continue
+        assert used == info["used"] == ref_used, name
+        # (c) a receiver running the reference reads the same bits from our frame as from the reference's
+        assert np.array_equal(orc.frame_extract_bits(stego, delta, n_ac)[:used],
+                              orc.frame_extract_bits(ref_stego, delta, n_ac)[:used]), name
+        # (d) PSNR
+        if np.isfinite(info["psnr"]):
+            assert abs(orc.psnr_u8(gray, stego) - info["psnr"]) <= PSNR_TOL_DB, name
+        else:
+            assert np.array_equal(stego, gray), name
+        # (e) extraction from the cover: identical except where c/delta is an exact rounding tie
+        packed, n_bits = batch.extract_frames(gray, delta, n_ac)
+        cov = np.unpackbits(packed, count=n_bits)
+        want = golden_bits(arrays, name, "ext_cover", info["ext_cover_len"])
+        ties = exact_tie_mask(gray, delta, n_ac).reshape(-1)
+        assert np.array_equal(cov[~ties], want[~ties]), name
+        _REPORT[name]["exact_ties_in_cover"] = int(ties.sum())
+
+
+def test_reference_ber_at_delta4_is_reproduced(golden):
+    """delta=4, n=3: the reference itself loses ~1.6 % of the payload.  Required:
+    identical bits to the oracle on the same frames, hence the same error positions."""
+    arrays, meta = golden
+    info, gray, payload = case_inputs(arrays, meta, "G7_d4_n3")
+    stego, used = batch.embed_frames(gray, 4, 3, payload)
+    packed, n_bits = batch.extract_frames(arrays["G7_d4_n3/stego"], 4, 3)
+    got = np.unpackbits(packed, count=n_bits)
+    assert np.array_equal(np.nonzero(got != payload)[0], arrays["G7_d4_n3/error_positions"])
+    packed, n_bits = batch.extract_frames(stego[0], 4, 3)
+    assert np.array_equal(np.unpackbits(packed, count=n_bits), orc.frame_extract_bits(stego[0], 4, 3))
+
+
+def test_stream_over_frames(golden):
+    arrays, meta = golden
+    info = meta["cases"]["G8_stream"]
+    frames = synth.synthetic_frames(3, 32, 48, seed=info["synth_seed"])
+    payload = arrays["G8_stream/payload"]
+    stego, used = batch.embed_frames(frames, info["delta"], info["n_ac"], payload)
+    assert used == info["used"]
+    for k in range(3):
+        assert np.array_equal(stego[k], arrays[f"G8_stream/stego{k}"]), k
+    assert np.array_equal(stego[2], frames[2])
+    packed, n_bits = batch.extract_frames(stego, info["delta"], info["n_ac"])
+    bits = np.unpackbits(packed, count=n_bits)
+    assert np.array_equal(bits[:used], payload)
+    for k in range(3):
+        cap = n_bits // 3
+        assert np.array_equal(np.packbits(bits[k * cap:(k + 1) * cap]), arrays[f"G8_stream/ext{k}"])
+    # bit_offset into a longer shared buffer (how ranks index one payload)
+    junk = synth.synthetic_bits(61, seed=3)
+    stego2, used2 = batch.embed_frames(frames, info["delta"], info["n_ac"], np.concatenate([junk, payload]),
+                                       bit_offset=61)
+    assert used2 == used and np.array_equal(stego2, stego)
+
+
+@pytest.mark.parametrize("shape,n_ac,delta,frames", [
+    ((1080, 1920), 10, 8, 3),     # BASELINE config 2 shape (n = app default 10)
+    ((2160, 3840), 3, 8, 2),      # BASELINE config 3 shape
+    ((480, 640), 10, 20, 2),      # BASELINE config 1 shape / app defaults
+    ((1080, 1920), 63, 16, 1),    # every AC coefficient
+    ((72, 200), 17, 9, 5),        # odd block counts: 9 x 25 blocks per frame
+])
+def test_full_size_round_trip_and_oracle_agreement(shape, n_ac, delta, frames):
+    h, w = shape
+    cover = synth.synthetic_frames(frames, h, w, seed=h + n_ac)
+    cap = batch.capacity_bits(frames, h, w, n_ac)
+    payload = synth.synthetic_bits(cap, seed=h + n_ac)
+    stego, used = batch.embed_frames(cover, delta, n_ac, payload)
+    assert used == cap
+    packed, n_bits = batch.extract_frames(stego, delta, n_ac)
+    got = np.unpackbits(packed, count=n_bits)
+    assert n_bits == cap
+    if n_ac <= 7 or delta >= 8 and n_ac < 63:
+        assert np.array_equal(got, payload)                      # payload BER 0
+    # oracle on the first and last frame: same extracted bits from the same stego; PSNR parity
+    per = cap // frames
+    for k in {0, frames - 1}:
+        assert np.array_equal(got[k * per:(k + 1) * per], orc.frame_extract_bits(stego[k], delta, n_ac))
+        _, ref_stego, _ = orc.frame_embed(cover[k], delta, payload[k * per:(k + 1) * per], n_ac)
+        a, b = orc.psnr_u8(cover[k], stego[k]), orc.psnr_u8(cover[k], ref_stego)
+        assert abs(a - b) <= PSNR_TOL_DB, (a, b)
+        _REPORT[f"full_{h}x{w}_n{n_ac}_d{delta}_frame{k}"] = {
+            "pixels": h * w, "pixels_differing_from_reference": int((stego[k] != ref_stego).sum()),
+            "psnr": a, "psnr_reference": b}
+        # the reference's receiver recovers the payload from our frame wherever it does from its own
+        assert np.array_equal(orc.frame_extract_bits(stego[k], delta, n_ac),
+                              orc.frame_extract_bits(ref_stego, delta, n_ac))
+
+
+def test_idempotent_and_deterministic():
+    cover = synth.synthetic_frames(2, 64, 64, seed=1)
+    payload = synth.synthetic_bits(2 * 64 * 5, seed=1)
+    a, _ = batch.embed_frames(cover, 8, 5, payload)
+    b, _ = batch.embed_frames(cover, 8, 5, payload)
+    assert np.array_equal(a, b)
+    # embedding the bits a frame already carries changes the quantisation index by nothing: the
+    # stego frame's own bits re-embedded give a frame that still decodes to them
+    packed, n = batch.extract_frames(a, 8, 5)
+    c, _ = batch.embed_frames(a, 8, 5, np.unpackbits(packed, count=n))
+    packed2, _ = batch.extract_frames(c, 8, 5)
+    assert np.array_equal(packed, packed2)
+
+
+# ---- device-pointer entry points: pitches, aliasing, helper kernels -----------------------------
+class _Dev:
+    def __init__(self, nbytes):
+        self.ptr = C.c_void_p()
+        native.check(native.load().svs_malloc(C.byref(self.ptr), nbytes), "svs_malloc")
+        self.nbytes = nbytes
+
+    def put(self, arr):
+        arr = np.ascontiguousarray(arr)
+        native.check(native.load().svs_memcpy_h2d(self.ptr, arr.ctypes.data, arr.nbytes, None), "h2d")
+        native.check(native.load().svs_stream_synchronize(None), "sync")
+
+    def get(self, nbytes=None, dtype=np.uint8):
+        out = np.empty(nbytes or self.nbytes, np.uint8)
+        native.check(native.load().svs_memcpy_d2h(out.ctypes.data, self.ptr, out.nbytes, None), "d2h")
+        native.check(native.load().svs_stream_synchronize(None), "sync")
+        return out.view(dtype)
+
+    def __del__(self):
+        native.load().svs_free(self.ptr)
+
+
+def test_pitched_planes_in_place_and_device_helpers():
+    lib = native.load()
+    f, h, w, n_ac, delta = 3, 40, 72, 6, 8
+    row_pitch, frame_pitch = 128, 128 * 40 + 256
+    planes = Planes(f, h, w, 0, row_pitch, frame_pitch)
+    span = f * frame_pitch
+    d_frames = _Dev(span)
+    native.check(lib.svs_memset(d_frames.ptr, 0xAB, span, None), "memset")
+    native.check(lib.svs_fill_synthetic_dev(d_frames.ptr, C.byref(planes), 99, 4, 16, 224, None), "fill")
+    host = d_frames.get()
+    want = synth.synthetic_frames(f, h, w, seed=99, first_frame=4)
+    view = np.stack([host[k * frame_pitch:k * frame_pitch + h * row_pitch].reshape(h, row_pitch)[:, :w]
+                     for k in range(f)])
+    assert np.array_equal(view, want)                       # on-device generator == NumPy generator
+    pad = host.copy()
+
+    cap = batch.capacity_bits(f, h, w, n_ac)
+    d_bits = _Dev((cap + 7) // 8 + 8)
+    native.check(lib.svs_fill_bits_dev(d_bits.ptr, cap, 99, 1000, None), "fill_bits")
+    bits = np.unpackbits(d_bits.get((cap + 7) // 8), count=cap)
+    assert np.array_equal(bits, synth.synthetic_bits(cap, seed=99, first_bit=1000))
+
+    used = batch.embed_device(d_frames.ptr, d_frames.ptr, planes, delta, n_ac, d_bits.ptr, 0, cap)   # in place
+    assert used == cap
+    after = d_frames.get()
+    stego = np.stack([after[k * frame_pitch:k * frame_pitch + h * row_pitch].reshape(h, row_pitch)[:, :w]
+                      for k in range(f)])
+    ref, _ = batch.embed_frames(want, delta, n_ac, bits)
+    assert np.array_equal(stego, ref)
+    mask = np.ones(span, bool)                              # padding bytes are never written
+    for k in range(f):
+        for y in range(h):
+            mask[k * frame_pitch + y * row_pitch:k * frame_pitch + y * row_pitch + w] = False
+    assert np.array_equal(after[mask], pad[mask])
+
+    d_out = _Dev((cap + 7) // 8 + 8)
+    n_bits = batch.extract_device(d_frames.ptr, planes, delta, n_ac, d_out.ptr, d_out.nbytes)
+    assert n_bits == cap
+    assert np.array_equal(np.unpackbits(d_out.get((cap + 7) // 8), count=cap), bits)
+
+    # on-device checkers used by bench.py
+    d_cnt = _Dev(8)
+    native.check(lib.svs_bit_errors_dev(d_out.ptr, d_bits.ptr, cap, d_cnt.ptr, None), "bit_errors")
+    assert int(d_cnt.get(dtype=np.uint64)[0]) == 0
+    flipped = np.packbits(bits ^ (np.arange(cap) % 97 == 0).astype(np.uint8))
+    d_bits.put(flipped)
+    native.check(lib.svs_bit_errors_dev(d_out.ptr, d_bits.ptr, cap, d_cnt.ptr, None), "bit_errors")
+    assert int(d_cnt.get(dtype=np.uint64)[0]) == int((np.arange(cap) % 97 == 0).sum())
+
+    d_cover = _Dev(span)
+    native.check(lib.svs_fill_synthetic_dev(d_cover.ptr, C.byref(planes), 99, 4, 16, 224, None), "fill")
+    d_sse = _Dev(8 * f)
+    native.check(lib.svs_frame_sse_dev(d_cover.ptr, d_frames.ptr, C.byref(planes), d_sse.ptr, None), "sse")
+    sse = d_sse.get(dtype=np.uint64)
+    want_sse = ((want.astype(np.int64) - stego.astype(np.int64)) ** 2).reshape(f, -1).sum(1)
+    assert np.array_equal(sse.astype(np.int64), want_sse)
+
+
+def test_error_codes():
+    lib = native.load()
+    bad = Planes(1, 12, 16, 0, 16, 12 * 16)
+    buf = np.zeros(64 * 64, np.uint8)
+    out = np.zeros(64, np.uint8)
+    got = C.c_uint64()
+    rc = lib.svs_extract(buf.ctypes.data, C.byref(bad), 8.0, 3, out.ctypes.data, out.size, C.byref(got))
+    assert rc == native.SVS_ERR_INVALID_ARG and b"multiples of 8" in lib.svs_last_error()
+    ok = Planes.contiguous(1, 64, 64)
+    rc = lib.svs_extract(buf.ctypes.data, C.byref(ok), 8.0, 3, out.ctypes.data, 2, C.byref(got))
+    assert rc == native.SVS_ERR_CAPACITY
+    rc = lib.svs_embed(None, None, C.byref(ok), 8.0, 3, None, 0, 0, C.byref(got))
+    assert rc == native.SVS_ERR_INVALID_ARG
+    with pytest.raises(native.SvsNativeError):
+        native.check(rc, "svs_embed")
+
+
+# ---- the drop-in operator ------------------------------------------------------------------------
+def test_drop_in_operator_matches_reference_contract(golden):
+    import config_and_setup as cs
+    arrays, meta = golden
+    info, gray, payload = case_inputs(arrays, meta, "G1_n10_d20")
+    pstr = orc.bits_to_str(payload)
+    g, stego, used = cs.proses_frame_qim_dct(gray, "embed", 20, pstr + "0101", num_ac_coeffs_to_use=10)
+    assert used == info["used"] and g is not gray and np.array_equal(g, gray)
+    assert stego.dtype == np.uint8 and stego.shape == gray.shape
+    assert abs(orc.psnr_u8(gray, stego) - info["psnr"]) <= PSNR_TOL_DB
+    text = cs.proses_frame_qim_dct(stego, "extract", 20, enable_debug_prints_extract=False, num_ac_coeffs_to_use=10)
+    assert isinstance(text, str) and text == pstr
+    assert cs.proses_frame_qim_dct(arrays["G1_n10_d20/stego"], "extract", 20, num_ac_coeffs_to_use=10) == \
+        orc.bits_to_str(golden_bits(arrays, "G1_n10_d20", "ext_stego", info["ext_stego_len"]))
+    assert cs.proses_frame_qim_dct(gray, "nonsense", 20) is None
+    with pytest.raises(ValueError, match=meta["bad_rank_error"]):
+        cs.proses_frame_qim_dct(np.zeros((8, 8, 4), np.uint8), "extract", 8)
+    g, s, used = cs.proses_frame_qim_dct(gray, "embed", 20, None, num_ac_coeffs_to_use=10)
+    assert used == 0 and np.array_equal(s, gray)
+    # default n = 63, delta as float
+    g, s, used = cs.proses_frame_qim_dct(gray, "embed", 7.5, pstr)
+    assert used == len(pstr)
+    assert cs.proses_frame_qim_dct(s, "extract", 7.5)[:used] == orc.frame_extract(s, 7.5, 63)[:used]
