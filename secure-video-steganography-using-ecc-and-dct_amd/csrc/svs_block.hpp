@@ -31,10 +31,9 @@
 
 namespace svs {
 
-// one row of a block: 8 pixels as two little-endian dwords
-struct alignas(8) Row8 {
-    uint32_t x, y;
-};
+// A block is held as two arrays of 8 little-endian dwords: rx[y] = pixels 0..3 of row y,
+// ry[y] = pixels 4..7.  (Plain scalar arrays on purpose: an array of 8-byte structs is not fully
+// scalarised by hipcc once 16-byte row loads are split into it, and ends up in LDS.)
 
 // cos(k*pi/16)/2 and 1/sqrt(8): the orthonormal DCT-II basis (scipy norm='ortho',
 // config_and_setup.py:135,168)
@@ -127,43 +126,41 @@ SVS_HD float ubyte_to_float(uint32_t w) {
     return (float)((w >> (8 * B)) & 0xffu);
 }
 
-// np.uint8(np.clip(v, 0, 255)) - clip, then C truncation (config_and_setup.py:171) - written into
-// byte B of `old`.
+// Store pixel value v - an INTEGER-valued float (pixel + floor(change)) - clipped to [0,255] into
+// byte B of `old`.  np.uint8(np.clip(x, 0, 255)) of the reference (config_and_setup.py:171) is
+// clip-then-truncate; for x = pixel + change with an integer pixel, trunc(clip(x)) ==
+// clip(pixel + floor(change)), which is what the callers pass in.
 template <int B>
 SVS_HD uint32_t put_pixel(float v, uint32_t old) {
-#if defined(__HIP_DEVICE_COMPILE__) && defined(SVS_USE_CVT_PK_U8)
-    // v_cvt_pk_u8_f32: enabled only after tests/test_gpu_primitives.py showed on gfx950 that it
-    // saturates to [0,255] and truncates toward zero
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(SVS_NO_CVT_PK_U8)
+    // v_cvt_pk_u8_f32 saturates to [0,255] and rounds to nearest even (measured on gfx950:
+    // profiles/r01_cvt_pk_u8_probe.json) - exact for the integer-valued input it gets here.
     return __builtin_amdgcn_cvt_pk_u8_f32(v, B, old);
 #else
-#if defined(__HIP_DEVICE_COMPILE__)
-    const float c = __builtin_amdgcn_fmed3f(v, 0.0f, 255.0f);
-#else
     const float c = v < 0.0f ? 0.0f : (v > 255.0f ? 255.0f : v);
-#endif
-    const uint32_t u = (uint32_t)c;  // truncates toward zero
+    const uint32_t u = (uint32_t)c;
     return (old & ~(0xffu << (8 * B))) | (u << (8 * B));
 #endif
 }
 
-// Forward transform of the coefficient rows u < U of one block held as 8 rows x 2 dwords.
+// Forward transform of the coefficient rows u < U of one block.
 // D[u][v] = sum_y sum_x a(u)a(v) p[y][x] cos((2y+1)u pi/16) cos((2x+1)v pi/16)
 // (vertical axis first, as the reference does: axis=0 then axis=1, config_and_setup.py:135).
 template <int U>
-SVS_HD void forward_rows(const Row8 (&raw)[8], float (&D)[U][8]) {
+SVS_HD void forward_rows(const uint32_t (&rx)[8], const uint32_t (&ry)[8], float (&D)[U][8]) {
     float V[U][8];
 #define SVS_COL(X, W, B)                                                                \
     {                                                                                   \
-        const float col[8] = {ubyte_to_float<B>(raw[0].W), ubyte_to_float<B>(raw[1].W), \
-                              ubyte_to_float<B>(raw[2].W), ubyte_to_float<B>(raw[3].W), \
-                              ubyte_to_float<B>(raw[4].W), ubyte_to_float<B>(raw[5].W), \
-                              ubyte_to_float<B>(raw[6].W), ubyte_to_float<B>(raw[7].W)}; \
+        const float col[8] = {ubyte_to_float<B>(W[0]), ubyte_to_float<B>(W[1]), \
+                              ubyte_to_float<B>(W[2]), ubyte_to_float<B>(W[3]), \
+                              ubyte_to_float<B>(W[4]), ubyte_to_float<B>(W[5]), \
+                              ubyte_to_float<B>(W[6]), ubyte_to_float<B>(W[7])}; \
         float out[8];                                                                   \
         fdct8<U>(col, out);                                                             \
         _Pragma("unroll") for (int u = 0; u < U; ++u) V[u][X] = out[u];                 \
     }
-    SVS_COL(0, x, 0) SVS_COL(1, x, 1) SVS_COL(2, x, 2) SVS_COL(3, x, 3)
-    SVS_COL(4, y, 0) SVS_COL(5, y, 1) SVS_COL(6, y, 2) SVS_COL(7, y, 3)
+    SVS_COL(0, rx, 0) SVS_COL(1, rx, 1) SVS_COL(2, rx, 2) SVS_COL(3, rx, 3)
+    SVS_COL(4, ry, 0) SVS_COL(5, ry, 1) SVS_COL(6, ry, 2) SVS_COL(7, ry, 3)
 #undef SVS_COL
 #pragma unroll
     for (int u = 0; u < U; ++u) fdct8<8>(V[u], D[u]);
@@ -202,11 +199,12 @@ SVS_HD uint32_t block_budget(uint64_t first, uint64_t n_bits, uint32_t n) {
     return left < n ? (uint32_t)left : n;
 }
 
-// Embed `nb` (1..n) payload bits, taken MSB-first from hi:lo, into the block held in raw[].
+// Embed `nb` (0..n) payload bits, taken MSB-first from hi:lo, into the block held in rx[]/ry[].
 template <int U, bool DBL>
-SVS_HD void embed_block(Row8 (&raw)[8], uint32_t n, uint32_t nb, uint32_t hi, uint32_t lo, const QimParams &qp) {
+SVS_HD void embed_block(uint32_t (&rx)[8], uint32_t (&ry)[8], uint32_t n, uint32_t nb, uint32_t hi, uint32_t lo,
+                        const QimParams &qp) {
     float D[U][8];
-    forward_rows<U>(raw, D);
+    forward_rows<U>(rx, ry, D);
 
     // QIM on flat coefficients 1..n: force the parity of round(c/delta) to the payload bit by
     // +1 (bit 1) / -1 (bit 0), requantise (config_and_setup.py:146-156); keep only the change.
@@ -229,7 +227,8 @@ SVS_HD void embed_block(Row8 (&raw)[8], uint32_t n, uint32_t nb, uint32_t hi, ui
     }
 
     // inverse transform of the change: horizontal on the U rows, then vertical per column with
-    // U non-zero inputs, added to the integer pixels and stored with clip + truncation (:171)
+    // U non-zero inputs; trunc(clip(pixel + change)) == clip(pixel + floor(change)) for an integer
+    // pixel (:171).  For U == 1 the change is the same in all 8 rows of a column.
     float P[U][8];
     idct8<8, true>(D[0], P[0]);
 #pragma unroll
@@ -242,18 +241,19 @@ SVS_HD void embed_block(Row8 (&raw)[8], uint32_t n, uint32_t nb, uint32_t hi, ui
         float out[8];                                                                \
         idct8<U, false>(in, out);                                                    \
         _Pragma("unroll") for (int y = 0; y < 8; ++y)                                \
-            raw[y].W = put_pixel<B>(ubyte_to_float<B>(raw[y].W) + out[y], raw[y].W); \
+            W[y] = put_pixel<B>(ubyte_to_float<B>(W[y]) + floorf(out[y]), W[y]);      \
     }
-    SVS_OUTCOL(0, x, 0) SVS_OUTCOL(1, x, 1) SVS_OUTCOL(2, x, 2) SVS_OUTCOL(3, x, 3)
-    SVS_OUTCOL(4, y, 0) SVS_OUTCOL(5, y, 1) SVS_OUTCOL(6, y, 2) SVS_OUTCOL(7, y, 3)
+    SVS_OUTCOL(0, rx, 0) SVS_OUTCOL(1, rx, 1) SVS_OUTCOL(2, rx, 2) SVS_OUTCOL(3, rx, 3)
+    SVS_OUTCOL(4, ry, 0) SVS_OUTCOL(5, ry, 1) SVS_OUTCOL(6, ry, 2) SVS_OUTCOL(7, ry, 3)
 #undef SVS_OUTCOL
 }
 
 // Parity bits of round(c_k/delta), k = 1..n, MSB-first into hi:lo (config_and_setup.py:160-161)
 template <int U>
-SVS_HD void extract_block(const Row8 (&raw)[8], uint32_t n, float delta_f, uint32_t &hi, uint32_t &lo) {
+SVS_HD void extract_block(const uint32_t (&rx)[8], const uint32_t (&ry)[8], uint32_t n, float delta_f, uint32_t &hi,
+                          uint32_t &lo) {
     float D[U][8];
-    forward_rows<U>(raw, D);
+    forward_rows<U>(rx, ry, D);
     hi = 0;
     lo = 0;
 #pragma unroll

@@ -5,6 +5,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 
@@ -40,6 +41,12 @@ svs::FastDiv make_div(uint32_t d) {
     return r;
 }
 
+// tuning knob: workgroup->tile chunking (see svs::tile_id); env override for experiments
+uint32_t env_chunk(const char *name, uint32_t dflt) {
+    const char *v = getenv(name);
+    return v ? (uint32_t)strtoul(v, nullptr, 10) : dflt;
+}
+
 int clamp_ac(int n_ac) { return n_ac < 0 ? 0 : (n_ac > 63 ? 63 : n_ac); }
 
 // validates the plane description and fills the kernel geometry
@@ -62,6 +69,8 @@ int make_geometry(const svs_planes *p, int n_ac, svs::Geometry *g, uint64_t *tot
     g->by_bpf = make_div((uint32_t)bpf);
     g->total_blocks = (uint32_t)total;
     g->n_ac = (uint32_t)clamp_ac(n_ac);
+    g->xcd_chunk = 0;
+    g->pad = 0;
     g->row_pitch = p->row_pitch;
     g->frame_pitch = p->frame_pitch;
     *total_blocks = total;
@@ -75,14 +84,52 @@ uint64_t span_bytes(const svs_planes *p) {
 
 using svs::rows_for;
 
-template <bool DBL>
-int launch_embed(int rows, dim3 grid, hipStream_t st, const uint8_t *gray, uint8_t *stego, const svs::Geometry &g,
+// ---- launch tuning (measured on MI355X, 600 x 4K frames; profiles/r01_ab_variants.txt) ----------------
+// * workgroup -> tile mapping (svs::tile_id): giving each XCD-group a contiguous eighth of the batch
+//   lifts the embed kernel ~+6..12 % (reads and writes of one XCD stay on neighbouring DRAM pages) and is
+//   never worse than the identity map; the read-only extract kernel at one coefficient row prefers runs of
+//   32 tiles per XCD (+3 %).
+// * two blocks per lane (16-byte accesses) pays only for the embed kernel at one coefficient row; with
+//   more rows the extra registers cost occupancy (n = 10: -17 %).
+// Environment overrides (experiments only): SVS_EMBED_XCD_CHUNK, SVS_EXTRACT_XCD_CHUNK, SVS_EMBED_BPL,
+// SVS_EXTRACT_BPL.
+constexpr uint32_t kEighth = 0xFFFFFFFFu;
+
+bool rows_allow_two_blocks(const svs_planes *p, const void *a, const void *b) {
+    return ((p->width / 8) % 2 == 0) && (p->row_pitch % 16 == 0) && (p->frame_pitch % 16 == 0) &&
+           ((uintptr_t)a % 16 == 0) && (b == nullptr || (uintptr_t)b % 16 == 0);
+}
+
+struct Tuning {
+    bool two_blocks;
+    uint32_t chunk;
+};
+
+Tuning embed_tuning(int rows, const svs_planes *p, const void *a, const void *b) {
+    Tuning t{rows == 1, kEighth};
+    t.two_blocks = env_chunk("SVS_EMBED_BPL", t.two_blocks ? 2 : 1) == 2;
+    t.chunk = env_chunk("SVS_EMBED_XCD_CHUNK", t.chunk);
+    t.two_blocks = t.two_blocks && rows_allow_two_blocks(p, a, b);
+    return t;
+}
+
+Tuning extract_tuning(int rows, const svs_planes *p, const void *a) {
+    Tuning t{false, rows == 1 ? 32u : kEighth};
+    t.two_blocks = env_chunk("SVS_EXTRACT_BPL", 1) == 2;
+    t.chunk = env_chunk("SVS_EXTRACT_XCD_CHUNK", t.chunk);
+    t.two_blocks = t.two_blocks && rows_allow_two_blocks(p, a, nullptr);
+    return t;
+}
+
+template <bool DBL, int BPL>
+int launch_embed(int rows, uint64_t total, hipStream_t st, const uint8_t *gray, uint8_t *stego, const svs::Geometry &g,
                  const svs::QimParams &qp, const uint32_t *bits, uint64_t bit_offset, uint64_t n_bits,
                  uint32_t n_words) {
-#define SVS_CASE(R)                                                                                          \
-    case R:                                                                                                  \
-        hipLaunchKernelGGL((svs::embed_kernel<R, DBL>), grid, dim3(256), 0, st, gray, stego, g, qp, bits,    \
-                           bit_offset, n_bits, n_words);                                                     \
+    const dim3 grid((uint32_t)((total + SVS_WG * BPL - 1) / (SVS_WG * BPL)));
+#define SVS_CASE(R)                                                                                            \
+    case R:                                                                                                    \
+        hipLaunchKernelGGL((svs::embed_kernel<R, DBL, BPL>), grid, dim3(SVS_WG), 0, st, gray, stego, g, qp, bits, \
+                           bit_offset, n_bits, n_words);                                                       \
         break;
     switch (rows) {
         SVS_CASE(1) SVS_CASE(2) SVS_CASE(3) SVS_CASE(4) SVS_CASE(5) SVS_CASE(6) SVS_CASE(7) SVS_CASE(8)
@@ -93,11 +140,13 @@ int launch_embed(int rows, dim3 grid, hipStream_t st, const uint8_t *gray, uint8
     return SVS_OK;
 }
 
-int launch_extract(int rows, dim3 grid, hipStream_t st, const uint8_t *gray, const svs::Geometry &g, float delta_f,
-                   uint8_t *out, uint64_t out_bytes) {
-#define SVS_CASE(R)                                                                                             \
-    case R:                                                                                                     \
-        hipLaunchKernelGGL((svs::extract_kernel<R>), grid, dim3(256), 0, st, gray, g, delta_f, out, out_bytes); \
+template <int BPL>
+int launch_extract(int rows, uint64_t total, hipStream_t st, const uint8_t *gray, const svs::Geometry &g,
+                   float delta_f, uint8_t *out, uint64_t out_bytes) {
+    const dim3 grid((uint32_t)((total + SVS_WG * BPL - 1) / (SVS_WG * BPL)));
+#define SVS_CASE(R)                                                                                                  \
+    case R:                                                                                                          \
+        hipLaunchKernelGGL((svs::extract_kernel<R, BPL>), grid, dim3(SVS_WG), 0, st, gray, g, delta_f, out, out_bytes); \
         break;
     switch (rows) {
         SVS_CASE(1) SVS_CASE(2) SVS_CASE(3) SVS_CASE(4) SVS_CASE(5) SVS_CASE(6) SVS_CASE(7) SVS_CASE(8)
@@ -215,7 +264,9 @@ int svs_embed_dev(const uint8_t *d_gray, uint8_t *d_stego, const svs_planes *pla
         if (bit_offset + use < bit_offset) return fail(SVS_ERR_INVALID_ARG, "bit_offset + n_bits overflows");
     }
     const hipStream_t st = (hipStream_t)stream;
-    const dim3 grid((uint32_t)((total + 255) / 256));
+    const Tuning tune = embed_tuning(rows_for(n), planes, d_gray, d_stego);
+    const bool two = tune.two_blocks;
+    g.xcd_chunk = tune.chunk;
     svs::QimParams qp;
     qp.delta_f = (float)delta;
     qp.delta_d = delta;
@@ -225,16 +276,20 @@ int svs_embed_dev(const uint8_t *d_gray, uint8_t *d_stego, const svs_planes *pla
         g.n_ac = 1;
         qp.delta_f = 1.0f;
         qp.delta_d = 1.0;
-        return launch_embed<false>(1, grid, st, d_gray, d_stego, g, qp, nullptr, 0, 0, 0);
+        return two ? launch_embed<false, 2>(1, total, st, d_gray, d_stego, g, qp, nullptr, 0, 0, 0)
+                   : launch_embed<false, 1>(1, total, st, d_gray, d_stego, g, qp, nullptr, 0, 0, 0);
     }
     const uint64_t last_byte = (bit_offset + use + 7) / 8;
     const uint64_t words = (last_byte + 3) / 4;
     if (words >= (1ull << 32)) return fail(SVS_ERR_INVALID_ARG, "payload too large for one call");
     const bool dbl = (double)qp.delta_f != delta;
-    int rc = dbl ? launch_embed<true>(rows_for(n), grid, st, d_gray, d_stego, g, qp,
-                                      reinterpret_cast<const uint32_t *>(d_bits_packed), bit_offset, use, (uint32_t)words)
-                 : launch_embed<false>(rows_for(n), grid, st, d_gray, d_stego, g, qp,
-                                       reinterpret_cast<const uint32_t *>(d_bits_packed), bit_offset, use, (uint32_t)words);
+    const uint32_t *bw = reinterpret_cast<const uint32_t *>(d_bits_packed);
+    const int rows = rows_for(n);
+    int rc;
+    if (dbl) rc = two ? launch_embed<true, 2>(rows, total, st, d_gray, d_stego, g, qp, bw, bit_offset, use, (uint32_t)words)
+                      : launch_embed<true, 1>(rows, total, st, d_gray, d_stego, g, qp, bw, bit_offset, use, (uint32_t)words);
+    else rc = two ? launch_embed<false, 2>(rows, total, st, d_gray, d_stego, g, qp, bw, bit_offset, use, (uint32_t)words)
+                  : launch_embed<false, 1>(rows, total, st, d_gray, d_stego, g, qp, bw, bit_offset, use, (uint32_t)words);
     if (rc) return rc;
     if (n_embedded) *n_embedded = use;
     return SVS_OK;
@@ -260,8 +315,12 @@ int svs_extract_dev(const uint8_t *d_gray, const svs_planes *planes, double delt
     if (!(delta > 0.0)) {
         SVS_HIP(hipMemsetAsync(d_bits_packed_out, 0, bytes, st));  // every bit '0' (config_and_setup.py:143-145)
     } else {
-        const dim3 grid((uint32_t)((total + 255) / 256));
-        if (int rc = launch_extract(rows_for(n), grid, st, d_gray, g, (float)delta, d_bits_packed_out, bytes)) return rc;
+        const Tuning tune = extract_tuning(rows_for(n), planes, d_gray);
+        g.xcd_chunk = tune.chunk;
+        const int rc = tune.two_blocks
+                           ? launch_extract<2>(rows_for(n), total, st, d_gray, g, (float)delta, d_bits_packed_out, bytes)
+                           : launch_extract<1>(rows_for(n), total, st, d_gray, g, (float)delta, d_bits_packed_out, bytes);
+        if (rc) return rc;
     }
     if (n_bits_out) *n_bits_out = cap;
     return SVS_OK;
@@ -389,6 +448,26 @@ int svs_bit_errors_dev(const uint8_t *d_a_packed, const uint8_t *d_b_packed, uin
     const uint32_t blocks = (uint32_t)((bytes + 255) / 256 < 2048 ? (bytes + 255) / 256 : 2048);
     hipLaunchKernelGGL(svs::bit_errors_kernel, dim3(blocks), dim3(256), 0, st, d_a_packed, d_b_packed, n_bits,
                        reinterpret_cast<unsigned long long *>(d_count));
+    SVS_HIP(hipGetLastError());
+    return SVS_OK;
+}
+
+// measurement hooks (not part of the product ABI): plain device copy / read streams, tools/ab_bench.py
+int svs_ref_copy_dev(const void *d_src, void *d_dst, uint64_t bytes, int mode, void *stream) {
+    const uint64_t n16 = bytes / 16;
+    const hipStream_t st = (hipStream_t)stream;
+    const auto *s = reinterpret_cast<const svs::u32x4 *>(d_src);
+    auto *d = reinterpret_cast<svs::u32x4 *>(d_dst);
+    if (mode == 0) hipLaunchKernelGGL(svs::copy_kernel<0>, dim3((uint32_t)((n16 + 255) / 256)), dim3(256), 0, st, s, d, n16);
+    else if (mode == 1) hipLaunchKernelGGL(svs::copy_kernel<1>, dim3(256 * 8), dim3(256), 0, st, s, d, n16);
+    else hipLaunchKernelGGL(svs::copy_kernel<2>, dim3(256 * 8), dim3(256), 0, st, s, d, n16);
+    SVS_HIP(hipGetLastError());
+    return SVS_OK;
+}
+
+int svs_ref_read_dev(const void *d_src, void *d_sink, uint64_t bytes, void *stream) {
+    hipLaunchKernelGGL(svs::read_kernel, dim3(256 * 8), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const svs::u32x4 *>(d_src), reinterpret_cast<uint32_t *>(d_sink), bytes / 16);
     SVS_HIP(hipGetLastError());
     return SVS_OK;
 }

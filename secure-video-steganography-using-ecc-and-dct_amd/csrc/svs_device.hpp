@@ -25,6 +25,8 @@ struct Geometry {
     FastDiv by_bpf;         // divide by blocks per frame
     uint32_t total_blocks;  // n_frames * blocks per frame   (< 2^31)
     uint32_t n_ac;          // 1..63
+    uint32_t xcd_chunk;     // tile_id() chunk (0 = identity)
+    uint32_t pad;
     int64_t row_pitch;
     int64_t frame_pitch;
 };
@@ -42,82 +44,163 @@ __device__ __forceinline__ int64_t block_offset(uint32_t gblock, const Geometry 
     return (int64_t)frame * g.frame_pitch + (int64_t)(brow * 8u) * g.row_pitch + (int64_t)(bcol * 8u);
 }
 
-__device__ __forceinline__ void load_block(const uint8_t *src, int64_t row_pitch, Row8 (&raw)[8]) {
-#pragma unroll
-    for (int y = 0; y < 8; ++y) raw[y] = *reinterpret_cast<const Row8 *>(src + y * row_pitch);
+#ifndef SVS_WG
+#define SVS_WG 256  // threads per workgroup of the embed / extract kernels
+#endif
+
+// Workgroup -> tile mapping.  Workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 names the
+// group that shares an XCD and its L2).  With chunk C > 0, the workgroups of one XCD take C consecutive
+// tiles at a time: tiles [g*8C + x*C, g*8C + (x+1)*C) go to XCD-group x in round g, so each XCD streams
+// runs of C adjacent tiles.  C = 0 is the identity; C = 0xFFFFFFFF gives every XCD-group one contiguous eighth of the grid.  Placement only affects speed, never results.
+__device__ __forceinline__ uint32_t tile_id(uint32_t chunk) {
+    const uint32_t i = blockIdx.x;
+    if (chunk == 0) return i;
+    if (chunk == 0xFFFFFFFFu) {  // one contiguous eighth of the grid per XCD-group (bijective for any grid)
+        const uint32_t n = gridDim.x, q = n / 8u, r = n % 8u, x = i % 8u;
+        return (x < r ? x * (q + 1u) : r * (q + 1u) + (x - r) * q) + i / 8u;
+    }
+    const uint32_t span = 8u * chunk;
+    const uint32_t full = (gridDim.x / span) * span;  // tiles covered by whole rounds
+    if (i >= full) return i;
+    const uint32_t x = i % 8u, j = i / 8u;
+    return (j / chunk) * span + x * chunk + (j % chunk);
 }
 
-__device__ __forceinline__ void store_block(uint8_t *dst, int64_t row_pitch, const Row8 (&raw)[8]) {
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+// Frames are streamed exactly once: non-temporal loads/stores keep them from displacing each other
+// in L2 / Infinity Cache (measured on MI355X: embed +5 %, extract +11 %, profiles/r01_ab_variants.txt)
+#if !defined(SVS_NO_NONTEMPORAL)
+#define SVS_LD(p) __builtin_nontemporal_load(p)
+#define SVS_ST(v, p) __builtin_nontemporal_store(v, p)
+#else
+#define SVS_LD(p) (*(p))
+#define SVS_ST(v, p) (*(p) = (v))
+#endif
+
+// Lanes own one block (8-byte row accesses) or two horizontally adjacent blocks A|B (BPL = 2:
+// one 16-byte access per row).  Rows travel as native 2- / 4-dword vectors; the per-block arithmetic
+// works on plain scalar arrays filled from them (this exact shape is what hipcc scalarises fully -
+// structs of rows updated in place ended up in LDS).
+template <int BPL>
+struct RowVec;
+template <>
+struct RowVec<1> { typedef u32x2 type; };
+template <>
+struct RowVec<2> { typedef u32x4 type; };
+
+template <int BPL>
+__device__ __forceinline__ void load_rows(const uint8_t *src, int64_t row_pitch, typename RowVec<BPL>::type (&v)[8]) {
 #pragma unroll
-    for (int y = 0; y < 8; ++y) *reinterpret_cast<Row8 *>(dst + y * row_pitch) = raw[y];
+    for (int r = 0; r < 8; ++r) v[r] = SVS_LD(reinterpret_cast<const typename RowVec<BPL>::type *>(src + r * row_pitch));
+}
+
+template <int BPL>
+__device__ __forceinline__ void store_rows(uint8_t *dst, int64_t row_pitch, const typename RowVec<BPL>::type (&v)[8]) {
+#pragma unroll
+    for (int r = 0; r < 8; ++r) SVS_ST(v[r], reinterpret_cast<typename RowVec<BPL>::type *>(dst + r * row_pitch));
 }
 
 // ---------------------------------------------------------------------------------------
-// EMBED: one lane = one block.  grid = ceil(total_blocks / 256) workgroups of 256.
+// EMBED: one lane = BPL adjacent blocks.  grid = ceil(total_blocks / (SVS_WG*BPL)) workgroups of SVS_WG.
+// BPL = 2 needs an even number of blocks per row and 16-byte aligned rows (host checks).
 // HBM traffic per block: 64 B read + 64 B written + n payload bits read.
 // ---------------------------------------------------------------------------------------
-template <int U, bool DBL>
-__global__ __launch_bounds__(256) void embed_kernel(const uint8_t *__restrict__ gray,
+template <int U, bool DBL, int BPL>
+__global__ __launch_bounds__(SVS_WG) void embed_kernel(const uint8_t *__restrict__ gray,
                                                     uint8_t *__restrict__ stego, const Geometry g,
                                                     const QimParams qp,
                                                     const uint32_t *__restrict__ bits,
                                                     const uint64_t bit_offset, const uint64_t n_bits,
                                                     const uint32_t n_words) {
-    const uint32_t gblock = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t gblock = (tile_id(g.xcd_chunk) * (uint32_t)SVS_WG + threadIdx.x) * BPL;
     if (gblock >= g.total_blocks) return;
     const int64_t off = block_offset(gblock, g);
 
-    Row8 raw[8];
-    load_block(gray + off, g.row_pitch, raw);
+    typename RowVec<BPL>::type v[8];
+    load_rows<BPL>(gray + off, g.row_pitch, v);
 
     const uint32_t n = g.n_ac;
-    const uint64_t first = (uint64_t)gblock * n;  // stream index of this block's first bit
-    const uint32_t nb = block_budget(first, n_bits, n);
-    if (nb == 0) {
+    const uint64_t first = (uint64_t)gblock * n;  // stream index of this lane's first bit
+    if (first >= n_bits) {
         // past the budget: byte-identical copy (the reference's loops `break`, :130,:132)
-        if (stego != gray) store_block(stego + off, g.row_pitch, raw);
+        if (stego != gray) store_rows<BPL>(stego + off, g.row_pitch, v);
         return;
     }
-    uint32_t hi, lo;
-    payload_window(bits, n_words, bit_offset + first, hi, lo);
-    embed_block<U, DBL>(raw, n, nb, hi, lo, qp);
-    store_block(stego + off, g.row_pitch, raw);
+    uint32_t ax[8], ay[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) { ax[r] = v[r].x; ay[r] = v[r].y; }
+    {
+        uint32_t hi, lo;
+        payload_window(bits, n_words, bit_offset + first, hi, lo);
+        embed_block<U, DBL>(ax, ay, n, block_budget(first, n_bits, n), hi, lo, qp);
+    }
+#pragma unroll
+    for (int r = 0; r < 8; ++r) { v[r].x = ax[r]; v[r].y = ay[r]; }
+    if constexpr (BPL == 2) {
+        uint32_t bx[8], by[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) { bx[r] = v[r].z; by[r] = v[r].w; }
+        // a budget of 0 (only the lane the payload ends in can see it here) yields an all-zero
+        // change, i.e. block B is stored back unchanged - no branch needed
+        uint32_t hi, lo;
+        payload_window(bits, n_words, bit_offset + first + n, hi, lo);
+        embed_block<U, DBL>(bx, by, n, block_budget(first + n, n_bits, n), hi, lo, qp);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) { v[r].z = bx[r]; v[r].w = by[r]; }
+    }
+    store_rows<BPL>(stego + off, g.row_pitch, v);
 }
 
 // ---------------------------------------------------------------------------------------
-// EXTRACT: one lane = one block; a wavefront's 64 blocks produce exactly n aligned 64-bit words
-// of the packed stream (stream bit = global block * n + i), assembled through a wave-private LDS
-// byte array and written with plain dword stores - no atomics, no pre-zeroed output.
-// HBM traffic per block: 64 B read + n bits written.
+// EXTRACT: one lane = BPL adjacent blocks; a wavefront's 64*BPL blocks produce exactly n*BPL
+// aligned 64-bit words of the packed stream (stream bit = global block * n + i), assembled through
+// a wave-private LDS byte array and written with plain dword stores - no atomics, no pre-zeroed
+// output.  HBM traffic per block: 64 B read + n bits written.
 // ---------------------------------------------------------------------------------------
-template <int U>
-__global__ __launch_bounds__(256) void extract_kernel(const uint8_t *__restrict__ gray, const Geometry g,
+template <int U, int BPL>
+__global__ __launch_bounds__(SVS_WG) void extract_kernel(const uint8_t *__restrict__ gray, const Geometry g,
                                                       const float delta_f, uint8_t *__restrict__ out,
                                                       const uint64_t out_bytes) {
-    __shared__ __attribute__((aligned(16))) uint8_t flags[4][64 * 64];
+    __shared__ __attribute__((aligned(16))) uint8_t flags[SVS_WG / 64][64 * 64 * BPL];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    const uint32_t gblock = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t tile = tile_id(g.xcd_chunk);
+    const uint32_t gblock = (tile * (uint32_t)SVS_WG + threadIdx.x) * BPL;
     const uint32_t n = g.n_ac;
 
-    uint32_t hi = 0, lo = 0;  // this block's bits, MSB first: bit i at position 63-i of hi:lo
+    // each block's bits, MSB first: bit i at position 63-i of hi:lo
+    uint32_t hi_a = 0, lo_a = 0, hi_b = 0, lo_b = 0;
     if (gblock < g.total_blocks) {
-        Row8 raw[8];
-        load_block(gray + block_offset(gblock, g), g.row_pitch, raw);
-        extract_block<U>(raw, n, delta_f, hi, lo);
+        typename RowVec<BPL>::type v[8];
+        load_rows<BPL>(gray + block_offset(gblock, g), g.row_pitch, v);
+        uint32_t ax[8], ay[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) { ax[r] = v[r].x; ay[r] = v[r].y; }
+        extract_block<U>(ax, ay, n, delta_f, hi_a, lo_a);
+        if constexpr (BPL == 2) {
+            uint32_t bx[8], by[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) { bx[r] = v[r].z; by[r] = v[r].w; }
+            extract_block<U>(bx, by, n, delta_f, hi_b, lo_b);
+        }
     }
 
-    // lane writes its n flag bytes at [lane*n, lane*n + n)
+    // lane writes its n*BPL flag bytes at [lane*BPL*n, ...)
     uint8_t *mine = &flags[wave][0];
 #pragma unroll
     for (int i = 0; i < 8 * U - 1; ++i) {
-        if ((uint32_t)i < n) mine[lane * n + i] = (uint8_t)window_bit(hi, lo, i);
+        if ((uint32_t)i < n) {
+            mine[lane * BPL * n + i] = (uint8_t)window_bit(hi_a, lo_a, i);
+            if constexpr (BPL == 2) mine[(lane * BPL + 1) * n + i] = (uint8_t)window_bit(hi_b, lo_b, i);
+        }
     }
     __syncthreads();
 
-    // 64*n flag bytes -> 2n dwords of packed stream; dword w of this wave covers flags [32w, 32w+32)
-    const uint64_t wave_first_block = (uint64_t)blockIdx.x * 256u + wave * 64u;
-    const uint64_t wave_byte0 = wave_first_block * n / 8u;  // 64*n bits per wave -> multiple of 8 bytes
-    for (uint32_t w = lane; w < 2u * n; w += 64u) {
+    // 64*BPL*n flag bytes -> 2*BPL*n dwords of packed stream; dword w covers flags [32w, 32w+32)
+    const uint64_t wave_first_block = ((uint64_t)tile * (uint32_t)SVS_WG + wave * 64u) * BPL;
+    const uint64_t wave_byte0 = wave_first_block * n / 8u;  // multiple of 8 bytes
+    for (uint32_t w = lane; w < 2u * BPL * n; w += 64u) {
         const uint4 f0 = *reinterpret_cast<const uint4 *>(mine + 32u * w);
         const uint4 f1 = *reinterpret_cast<const uint4 *>(mine + 32u * w + 16u);
         // four 0/1 bytes (first flag in the low byte) -> nibble with the first flag as MSB
@@ -165,10 +248,10 @@ __global__ __launch_bounds__(256) void fill_synthetic_kernel(uint8_t *__restrict
             const uint32_t v = lo + lowbias32(base + x * 0xC2B2AE35u) % span;
             px[j >> 2] |= v << (8 * (j & 3));
         }
-        Row8 r8;
+        u32x2 r8;
         r8.x = px[0];
         r8.y = px[1];
-        *reinterpret_cast<Row8 *>(frames + (int64_t)f * frame_pitch + (int64_t)y * row_pitch + xg * 8u) = r8;
+        *reinterpret_cast<u32x2 *>(frames + (int64_t)f * frame_pitch + (int64_t)y * row_pitch + xg * 8u) = r8;
     }
 }
 
@@ -199,8 +282,8 @@ __global__ __launch_bounds__(256) void frame_sse_kernel(const uint8_t *__restric
          t += (uint64_t)gridDim.x * blockDim.x) {
         const uint32_t xg = (uint32_t)(t % groups_per_row), y = (uint32_t)(t / groups_per_row);
         const int64_t off = (int64_t)f * frame_pitch + (int64_t)y * row_pitch + xg * 8u;
-        const Row8 va = *reinterpret_cast<const Row8 *>(a + off);
-        const Row8 vb = *reinterpret_cast<const Row8 *>(b + off);
+        const u32x2 va = *reinterpret_cast<const u32x2 *>(a + off);
+        const u32x2 vb = *reinterpret_cast<const u32x2 *>(b + off);
         const uint32_t wa[2] = {va.x, va.y}, wb[2] = {vb.x, vb.y};
         uint32_t s = 0;
 #pragma unroll
@@ -228,6 +311,43 @@ __global__ __launch_bounds__(256) void bit_errors_kernel(const uint8_t *__restri
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
     if ((threadIdx.x & 63u) == 0 && acc) atomicAdd(count, acc);
+}
+
+// ---- reference streams for tools/ab_bench.py: what plain copies / reads reach on the same box ----
+// mode 0: one 16-byte element per thread, non-temporal;  mode 1: grid-stride, 4 x 16 B in flight per
+// thread, non-temporal;  mode 2: as 1 with default cache policy
+template <int MODE>
+__global__ __launch_bounds__(256) void copy_kernel(const u32x4 *__restrict__ src, u32x4 *__restrict__ dst, uint64_t n16) {
+    if constexpr (MODE == 0) {
+        const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+        if (i < n16) __builtin_nontemporal_store(__builtin_nontemporal_load(src + i), dst + i);
+    } else {
+        const uint64_t stride = (uint64_t)gridDim.x * 256u;
+        uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+        for (; i + 3 * stride < n16; i += 4 * stride) {
+            u32x4 a, b, c, d;
+            if constexpr (MODE == 1) {
+                a = __builtin_nontemporal_load(src + i); b = __builtin_nontemporal_load(src + i + stride);
+                c = __builtin_nontemporal_load(src + i + 2 * stride); d = __builtin_nontemporal_load(src + i + 3 * stride);
+                __builtin_nontemporal_store(a, dst + i); __builtin_nontemporal_store(b, dst + i + stride);
+                __builtin_nontemporal_store(c, dst + i + 2 * stride); __builtin_nontemporal_store(d, dst + i + 3 * stride);
+            } else {
+                a = src[i]; b = src[i + stride]; c = src[i + 2 * stride]; d = src[i + 3 * stride];
+                dst[i] = a; dst[i + stride] = b; dst[i + 2 * stride] = c; dst[i + 3 * stride] = d;
+            }
+        }
+        for (; i < n16; i += stride) dst[i] = src[i];
+    }
+}
+
+// read-only stream: xor-reduce, one dword written per workgroup (keeps the loads alive)
+__global__ __launch_bounds__(256) void read_kernel(const u32x4 *__restrict__ src, uint32_t *__restrict__ sink, uint64_t n16) {
+    const uint64_t stride = (uint64_t)gridDim.x * 256u;
+    u32x4 acc = {0, 0, 0, 0};
+    for (uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x; i < n16; i += stride)
+        acc ^= __builtin_nontemporal_load(src + i);
+    const uint32_t v = acc.x ^ acc.y ^ acc.z ^ acc.w;
+    if (v == 0x12345678u) sink[blockIdx.x] = v;
 }
 
 // probe used by tests/test_gpu_primitives.py: what v_cvt_pk_u8_f32 does with a value

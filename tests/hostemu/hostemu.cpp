@@ -12,13 +12,29 @@
 
 namespace {
 
+struct Blk {
+    uint32_t x[8], y[8];
+    void load(const uint8_t *p, size_t pitch) {
+        for (int r = 0; r < 8; ++r) {
+            std::memcpy(&x[r], p + r * pitch, 4);
+            std::memcpy(&y[r], p + r * pitch + 4, 4);
+        }
+    }
+    void store(uint8_t *p, size_t pitch) const {
+        for (int r = 0; r < 8; ++r) {
+            std::memcpy(p + r * pitch, &x[r], 4);
+            std::memcpy(p + r * pitch + 4, &y[r], 4);
+        }
+    }
+};
+
 template <int U>
-void embed_u(svs::Row8 (&raw)[8], uint32_t n, uint32_t nb, uint32_t hi, uint32_t lo, const svs::QimParams &qp, bool dbl) {
-    if (dbl) svs::embed_block<U, true>(raw, n, nb, hi, lo, qp);
-    else svs::embed_block<U, false>(raw, n, nb, hi, lo, qp);
+void embed_u(Blk &raw, uint32_t n, uint32_t nb, uint32_t hi, uint32_t lo, const svs::QimParams &qp, bool dbl) {
+    if (dbl) svs::embed_block<U, true>(raw.x, raw.y, n, nb, hi, lo, qp);
+    else svs::embed_block<U, false>(raw.x, raw.y, n, nb, hi, lo, qp);
 }
 
-void embed_dispatch(int rows, svs::Row8 (&raw)[8], uint32_t n, uint32_t nb, uint32_t hi, uint32_t lo,
+void embed_dispatch(int rows, Blk &raw, uint32_t n, uint32_t nb, uint32_t hi, uint32_t lo,
                     const svs::QimParams &qp, bool dbl) {
     switch (rows) {
         case 1: embed_u<1>(raw, n, nb, hi, lo, qp, dbl); break;
@@ -32,16 +48,16 @@ void embed_dispatch(int rows, svs::Row8 (&raw)[8], uint32_t n, uint32_t nb, uint
     }
 }
 
-void extract_dispatch(int rows, const svs::Row8 (&raw)[8], uint32_t n, float d, uint32_t &hi, uint32_t &lo) {
+void extract_dispatch(int rows, const Blk &raw, uint32_t n, float d, uint32_t &hi, uint32_t &lo) {
     switch (rows) {
-        case 1: svs::extract_block<1>(raw, n, d, hi, lo); break;
-        case 2: svs::extract_block<2>(raw, n, d, hi, lo); break;
-        case 3: svs::extract_block<3>(raw, n, d, hi, lo); break;
-        case 4: svs::extract_block<4>(raw, n, d, hi, lo); break;
-        case 5: svs::extract_block<5>(raw, n, d, hi, lo); break;
-        case 6: svs::extract_block<6>(raw, n, d, hi, lo); break;
-        case 7: svs::extract_block<7>(raw, n, d, hi, lo); break;
-        default: svs::extract_block<8>(raw, n, d, hi, lo); break;
+        case 1: svs::extract_block<1>(raw.x, raw.y, n, d, hi, lo); break;
+        case 2: svs::extract_block<2>(raw.x, raw.y, n, d, hi, lo); break;
+        case 3: svs::extract_block<3>(raw.x, raw.y, n, d, hi, lo); break;
+        case 4: svs::extract_block<4>(raw.x, raw.y, n, d, hi, lo); break;
+        case 5: svs::extract_block<5>(raw.x, raw.y, n, d, hi, lo); break;
+        case 6: svs::extract_block<6>(raw.x, raw.y, n, d, hi, lo); break;
+        case 7: svs::extract_block<7>(raw.x, raw.y, n, d, hi, lo); break;
+        default: svs::extract_block<8>(raw.x, raw.y, n, d, hi, lo); break;
     }
 }
 
@@ -68,12 +84,12 @@ uint64_t emu_embed(const uint8_t *gray, uint8_t *stego, int F, int H, int W, dou
         const uint64_t f = gb / bpf, b = gb % bpf;
         const uint64_t by = b / (W / 8), bx = b % (W / 8);
         uint8_t *p = stego + f * (uint64_t)H * W + by * 8 * W + bx * 8;
-        svs::Row8 raw[8];
-        for (int y = 0; y < 8; ++y) std::memcpy(&raw[y], p + (size_t)y * W, 8);
+        Blk raw;
+        raw.load(p, (size_t)W);
         uint32_t hi, lo;
         svs::payload_window(reinterpret_cast<const uint32_t *>(bits), n_words, bit_offset + first, hi, lo);
         embed_dispatch(svs::rows_for(n), raw, (uint32_t)n, nb, hi, lo, qp, dbl);
-        for (int y = 0; y < 8; ++y) std::memcpy(p + (size_t)y * W, &raw[y], 8);
+        raw.store(p, (size_t)W);
     }
     return use;
 }
@@ -91,8 +107,8 @@ uint64_t emu_extract(const uint8_t *gray, int F, int H, int W, double delta, int
         const uint64_t f = gb / bpf, b = gb % bpf;
         const uint64_t by = b / (W / 8), bx = b % (W / 8);
         const uint8_t *p = gray + f * (uint64_t)H * W + by * 8 * W + bx * 8;
-        svs::Row8 raw[8];
-        for (int y = 0; y < 8; ++y) std::memcpy(&raw[y], p + (size_t)y * W, 8);
+        Blk raw;
+        raw.load(p, (size_t)W);
         uint32_t hi, lo;
         extract_dispatch(svs::rows_for(n), raw, (uint32_t)n, (float)delta, hi, lo);
         for (int i = 0; i < n; ++i) out_flags[gb * n + i] = (uint8_t)svs::window_bit(hi, lo, i);
@@ -102,10 +118,10 @@ uint64_t emu_extract(const uint8_t *gray, int F, int H, int W, double delta, int
 
 // forward coefficients of one block (for the DCT accuracy test): D[8][8]
 void emu_forward_block(const uint8_t *block64, float *D64) {
-    svs::Row8 raw[8];
-    for (int y = 0; y < 8; ++y) std::memcpy(&raw[y], block64 + 8 * y, 8);
+    Blk raw;
+    raw.load(block64, 8);
     float D[8][8];
-    svs::forward_rows<8>(raw, D);
+    svs::forward_rows<8>(raw.x, raw.y, D);
     std::memcpy(D64, D, sizeof D);
 }
 

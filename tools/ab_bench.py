@@ -1,0 +1,99 @@
+#!/usr/bin/env python3
+"""A/B timing of kernel build variants in ONE process, interleaved rounds (guide rule 24).
+
+usage: python tools/ab_bench.py [--frames 600] [--rounds 15] [--n-ac 3] [--delta 8] [--h 2160 --w 3840] lib1.so lib2.so ...
+Reports median / min kernel time (HIP events on the launch stream) and algorithmic GB/s, and checks that
+every variant produces byte-identical stego frames and extracted bits.
+"""
+import argparse, ctypes as C, hashlib, os, statistics, sys
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(REPO, "secure-video-steganography-using-ecc-and-dct_amd"))
+import torch
+from svsdct import native
+from svsdct.native import Planes
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--frames", type=int, default=600); ap.add_argument("--rounds", type=int, default=15)
+ap.add_argument("--n-ac", type=int, default=3); ap.add_argument("--delta", type=float, default=8.0)
+ap.add_argument("--h", type=int, default=2160); ap.add_argument("--w", type=int, default=3840)
+ap.add_argument("--chunks", default="", help="comma list: sweep SVS_*_XCD_CHUNK on the first lib")
+ap.add_argument("libs", nargs="+")
+a = ap.parse_args()
+
+def load(path):
+    lib = C.CDLL(os.path.abspath(path))
+    for name, (res, args) in native.SIGNATURES.items():
+        fn = getattr(lib, name); fn.restype = res; fn.argtypes = args
+    return lib
+
+libs = [(os.path.basename(p).replace("libsvsdct", "").replace(".so", "") or "base", load(p), None) for p in a.libs]
+if a.chunks:
+    libs = [(f"chunk{c}", libs[0][1], c) for c in a.chunks.split(",")]
+dev = torch.device("cuda", 0); torch.cuda.set_device(0)
+F, H, W, n = a.frames, a.h, a.w, a.n_ac
+planes = Planes.contiguous(F, H, W)
+cap = F * (H // 8) * (W // 8) * min(n, 63); nbytes = (cap + 7) // 8
+gray = torch.empty((F, H, W), dtype=torch.uint8, device=dev); stego = torch.empty_like(gray)
+pay = torch.zeros(nbytes + 8, dtype=torch.uint8, device=dev); ext = torch.zeros(nbytes + 8, dtype=torch.uint8, device=dev)
+st = torch.cuda.current_stream().cuda_stream
+l0 = libs[0][1]
+assert l0.svs_fill_synthetic_dev(gray.data_ptr(), C.byref(planes), 20250620, 0, 16, 224, st) == 0
+assert l0.svs_fill_bits_dev(pay.data_ptr(), cap, 20250620, 0, st) == 0
+torch.cuda.synchronize()
+times = {name: {"embed": [], "extract": []} for name, _, _ in libs}
+digests = {}
+done = C.c_uint64()
+for r in range(a.rounds + 2):
+    for name, lib, chunk in libs:
+        if chunk is not None:
+            os.environ["SVS_EMBED_XCD_CHUNK"] = chunk; os.environ["SVS_EXTRACT_XCD_CHUNK"] = chunk
+        e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        e[0].record()
+        rc = lib.svs_embed_dev(gray.data_ptr(), stego.data_ptr(), C.byref(planes), a.delta, n, pay.data_ptr(), 0, cap, C.byref(done), st)
+        assert rc == 0, lib.svs_last_error()
+        e[1].record()
+        rc = lib.svs_extract_dev(stego.data_ptr(), C.byref(planes), a.delta, n, ext.data_ptr(), ext.numel(), C.byref(done), st)
+        assert rc == 0, lib.svs_last_error()
+        e[2].record()
+        torch.cuda.synchronize()
+        if r >= 2:
+            times[name]["embed"].append(e[0].elapsed_time(e[1])); times[name]["extract"].append(e[1].elapsed_time(e[2]))
+        if r == 0:
+            h = hashlib.sha256(stego[:2].cpu().numpy().tobytes()); h.update(ext[:nbytes].cpu().numpy().tobytes())
+            digests[name] = h.hexdigest()[:16]
+            same = bool(torch.equal(ext[:nbytes], pay[:nbytes]))
+            digests[name] += " roundtrip_ok" if same else " ROUNDTRIP_MISMATCH"
+# ceilings on this box: (1) the embed kernel's own access pattern with the arithmetic skipped (n_bits = 0 ->
+# every lane copies its block), (2) torch's contiguous device-to-device copy
+ceil = {"pattern_copy": [], "torch_copy": [], "copy16_nt": [], "copy_gridstride_nt": [], "copy_gridstride": [], "read_nt": []}
+l0.svs_ref_copy_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p]
+l0.svs_ref_read_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
+sink = torch.zeros(4096, dtype=torch.int32, device=dev)
+for r in range(a.rounds + 2):
+    e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    e[0].record()
+    assert libs[0][1].svs_embed_dev(gray.data_ptr(), stego.data_ptr(), C.byref(planes), a.delta, n, pay.data_ptr(), 0, 0, C.byref(done), st) == 0
+    e[1].record()
+    stego.copy_(gray)
+    e[2].record()
+    ex = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
+    ex[0].record()
+    for m in range(3):
+        assert l0.svs_ref_copy_dev(gray.data_ptr(), stego.data_ptr(), gray.numel(), m, st) == 0
+        ex[m + 1].record()
+    assert l0.svs_ref_read_dev(gray.data_ptr(), sink.data_ptr(), gray.numel(), st) == 0
+    ex[4].record()
+    torch.cuda.synchronize()
+    if r >= 2:
+        ceil["pattern_copy"].append(e[0].elapsed_time(e[1])); ceil["torch_copy"].append(e[1].elapsed_time(e[2]))
+        for m, k in enumerate(["copy16_nt", "copy_gridstride_nt", "copy_gridstride"]):
+            ceil[k].append(ex[m].elapsed_time(ex[m + 1]))
+        ceil["read_nt"].append(2 * ex[3].elapsed_time(ex[4]))   # x2: reported below against 2 B/px like the copies
+eb, xb = F * H * W * 2 + nbytes, F * H * W + nbytes
+for k, v in ceil.items():
+    print(f"{k:18s} copy  med {statistics.median(v):7.4f} min {min(v):7.4f} ms -> {F*H*W*2/statistics.median(v)/1e6:7.1f} GB/s")
+print(f"{F} frames {W}x{H} n={n} delta={a.delta:g}; {a.rounds} interleaved rounds")
+for name, _, _ in libs:
+    te, tx = times[name]["embed"], times[name]["extract"]
+    print(f"{name:18s} embed med {statistics.median(te):7.4f} min {min(te):7.4f} ms -> {eb/statistics.median(te)/1e6:7.1f} GB/s | "
+          f"extract med {statistics.median(tx):7.4f} min {min(tx):7.4f} ms -> {xb/statistics.median(tx)/1e6:7.1f} GB/s | {digests[name]}")
