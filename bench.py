@@ -65,6 +65,7 @@ def main():
     import ctypes as C
 
     from svsdct import batch, native
+    from svsdct import dist as sdist
     from svsdct.native import Planes
     lib = native.load()                      # raises if the HIP library is missing - no fallback
     native.ensure_device(local_rank)
@@ -100,7 +101,7 @@ def main():
         if ev:
             ev[2].record()
         if world > 1:
-            dist.gather(extracted[:nbytes], gathered, dst=0)     # RCCL: packed bits to rank 0, rank order
+            sdist.gather_packed(extracted, nbytes, dst=0, recv=gathered)   # RCCL: packed bits to rank 0, rank order
         return used, got
 
     for _ in range(args.warmup):

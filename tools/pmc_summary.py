@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""Summarise the rocprofv3 --pmc passes of tools/gpu_pmc.sh into profiles/<tag>_pmc_summary.json and
+profiles/hbm_traffic.json (the per-launch HBM bytes bench.py reports as roofline.traffic).
+
+Corrections applied, as MI355X_MICROARCH.md (HBM section) prescribes:
+  * FETCH_SIZE / WRITE_SIZE are in KiB;
+  * on gfx950 FETCH_SIZE reports exactly 1/2 of the bytes of a coalesced stream -> doubled.  The factor is
+    CALIBRATED in the same run on frame_sse_kernel, which reads a known 2*F*H*W bytes with the same 8-byte-per-lane
+    row accesses (TCC_EA0_RDREQ_sum * 128 B is reported beside it as an independent count);
+  * WRITE_SIZE is exact for these full-line streaming stores (checked on fill_synthetic_kernel's known F*H*W bytes).
+"""
+import collections, csv, glob, json, os, sys
+repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(repo, "gpurun_out")
+tag = sys.argv[2] if len(sys.argv) > 2 else "r01"
+F, H, W, n = 600, 2160, 3840, 3
+agg = collections.defaultdict(list)
+for f in glob.glob(os.path.join(src, "pmc_*", "*", "*_counter_collection.csv")):
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("svs::", "")
+        k = k.split("<")[0]
+        agg[(k, r["Counter_Name"])].append(float(r["Counter_Value"]))
+mean = {k: sum(v) / len(v) for k, v in agg.items()}
+px = F * H * W
+known_read = 2 * px                     # frame_sse_kernel
+fetch_scale = known_read / (mean[("frame_sse_kernel", "FETCH_SIZE")] * 1024)
+write_scale = px / (mean[("fill_synthetic_kernel", "WRITE_SIZE")] * 1024)
+out = {"workload": {"frames": F, "height": H, "width": W, "n_ac": n},
+       "calibration": {"FETCH_SIZE_scale_from_frame_sse_kernel": fetch_scale,
+                       "WRITE_SIZE_scale_from_fill_synthetic_kernel": write_scale}, "kernels": {}}
+for kern, alg in (("embed_kernel", 2 * px + px * n // 512), ("extract_kernel", px + px * n // 512)):
+    rd = mean[(kern, "FETCH_SIZE")] * 1024 * 2.0
+    wr = mean[(kern, "WRITE_SIZE")] * 1024
+    out["kernels"][kern] = {
+        "algorithmic_bytes_per_launch": alg,
+        "hbm_read_bytes_FETCH_SIZE_x2": rd, "hbm_read_bytes_RDREQ_x128": mean.get((kern, "TCC_EA0_RDREQ_sum"), 0) * 128,
+        "hbm_write_bytes_WRITE_SIZE": wr, "hbm_write_bytes_WRREQ_x64": mean.get((kern, "TCC_EA0_WRREQ_sum"), 0) * 64,
+        "hbm_bytes_per_launch": rd + wr, "traffic_over_algorithmic": (rd + wr) / alg,
+        "SQ_INSTS_VALU_per_wave": mean.get((kern, "SQ_INSTS_VALU"), 0) / max(mean.get((kern, "SQ_WAVES"), 1), 1),
+        "effective_clock_GHz_note": "GRBM_GUI_ACTIVE/8/kernel time; see raw counters",
+        "raw_means": {c: v for (k, c), v in mean.items() if k == kern}}
+with open(os.path.join(repo, "profiles", f"{tag}_pmc_summary.json"), "w") as fh:
+    json.dump(out, fh, indent=1, sort_keys=True)
+with open(os.path.join(repo, "profiles", "hbm_traffic.json"), "w") as fh:
+    json.dump({"frames": F, "height": H, "width": W, "n_ac": n,
+               "embed_bytes_per_launch": out["kernels"]["embed_kernel"]["hbm_bytes_per_launch"],
+               "extract_bytes_per_launch": out["kernels"]["extract_kernel"]["hbm_bytes_per_launch"],
+               "source": f"profiles/{tag}_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, tools/gpu_pmc.sh)"},
+              fh, indent=1)
+print(json.dumps({k: {kk: vv for kk, vv in v.items() if kk != "raw_means"} for k, v in out["kernels"].items()}, indent=1))
