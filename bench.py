@@ -43,6 +43,9 @@ def parse_args():
     ap.add_argument("--n-ac", type=int, default=3)
     ap.add_argument("--delta", type=float, default=8.0)
     ap.add_argument("--cpu-frames", type=int, default=6, help="frames in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--rehearse-gloo", action="store_true",
+                    help="rank-logic rehearsal on a box with fewer GPUs than ranks: gloo backend, ranks share "
+                         "GPUs, collectives staged through host memory (numbers are NOT bench results)")
     return ap.parse_args()
 
 
@@ -56,11 +59,20 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    # launched by torch.distributed.run (RANK set): take the collective path even with one rank, so a
+    # 1-GPU box can exercise the RCCL calls; plain `python bench.py` is the N = 1 line without a process group
+    use_dist = world > 1 or (os.environ.get("SVS_BENCH_FORCE_DIST") == "1" and "RANK" in os.environ)
+    if args.rehearse_gloo:
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.rehearse_gloo:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)     # "nccl" is RCCL on ROCm
+    cdev = torch.device("cpu") if args.rehearse_gloo else dev     # where collective buffers live
 
     import ctypes as C
 
@@ -79,50 +91,74 @@ def main():
     gray = torch.empty((F, H, W), dtype=torch.uint8, device=dev)
     stego = torch.empty_like(gray)
     payload = torch.zeros(nbytes + 8 - nbytes % 4, dtype=torch.uint8, device=dev)
-    extracted = torch.zeros(nbytes + 8 - nbytes % 4, dtype=torch.uint8, device=dev)
+    # extracted bits are double-buffered so that the gather of step k overlaps the kernels of step k+1
+    ext_bufs = [torch.zeros(nbytes + 8 - nbytes % 4, dtype=torch.uint8, device=dev) for _ in range(2 if use_dist else 1)]
     first_frame = rank * F
     native.check(lib.svs_fill_synthetic_dev(gray.data_ptr(), C.byref(planes), SEED, first_frame, 16, 224, stream),
                  "fill_synthetic")
     native.check(lib.svs_fill_bits_dev(payload.data_ptr(), cap, SEED, rank * cap, stream), "fill_bits")
-    gathered = None
-    if world > 1:
-        gathered = [torch.empty(nbytes, dtype=torch.uint8, device=dev) for _ in range(world)] if rank == 0 else None
+    gathered = [None, None]
+    if use_dist and rank == 0:
+        gathered = [[torch.empty(nbytes, dtype=torch.uint8, device=cdev) for _ in range(world)] for _ in range(2)]
+    pending = [None, None]
     torch.cuda.synchronize()
+    step_no = [0]
 
     def step(ev=None):
+        slot = step_no[0] % len(ext_bufs)
+        step_no[0] += 1
+        extracted = ext_bufs[slot]
         if ev:
             ev[0].record()
         used = batch.embed_device(gray.data_ptr(), stego.data_ptr(), planes, delta, n_ac, payload.data_ptr(), 0, cap,
                                   stream)
         if ev:
             ev[1].record()
+        if pending[slot] is not None:
+            pending[slot].wait()          # the gather that last read this buffer must have finished
+            pending[slot] = None
         got = batch.extract_device(stego.data_ptr(), planes, delta, n_ac, extracted.data_ptr(), extracted.numel(),
                                    stream)
         if ev:
             ev[2].record()
-        if world > 1:
-            sdist.gather_packed(extracted, nbytes, dst=0, recv=gathered)   # RCCL: packed bits to rank 0, rank order
+        if use_dist:
+            # the path's one collective (RCCL over xGMI): packed bits of every rank to rank 0, in rank order;
+            # asynchronous, so it runs beside the next step's kernels
+            if args.rehearse_gloo:
+                sdist.gather_packed(extracted.cpu(), nbytes, dst=0, recv=gathered[slot])
+            else:
+                pending[slot] = dist.gather(extracted[:nbytes], gathered[slot] if rank == 0 else None, dst=0,
+                                            async_op=True)
         return used, got
 
+    def drain():
+        for i, w in enumerate(pending):
+            if w is not None:
+                w.wait()
+                pending[i] = None
+
+    used = got = cap
     for _ in range(args.warmup):
         used, got = step()
-    assert (used, got) == (cap, cap) or args.warmup == 0
+    drain()
+    assert (used, got) == (cap, cap)
 
     events = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for k in range(args.steps):
         step(events[k])
+    drain()                                  # every gather of the timed steps has completed
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if use_dist:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -131,23 +167,25 @@ def main():
 
     # ---- correctness of what was just timed (outside the timed region) -------------------------
     cnt = torch.zeros(1, dtype=torch.int64, device=dev)
+    last = (step_no[0] - 1) % len(ext_bufs)
+    extracted = ext_bufs[last]
     native.check(lib.svs_bit_errors_dev(extracted.data_ptr(), payload.data_ptr(), cap, cnt.data_ptr(), stream), "ber")
     sse = torch.zeros(F, dtype=torch.int64, device=dev)
     native.check(lib.svs_frame_sse_dev(gray.data_ptr(), stego.data_ptr(), C.byref(planes), sse.data_ptr(), stream),
                  "sse")
     torch.cuda.synchronize()
     bit_errors = int(cnt.item())
-    if world > 1:
-        t = torch.tensor([bit_errors], dtype=torch.int64, device=dev)
+    if use_dist:
+        t = torch.tensor([bit_errors], dtype=torch.int64, device=cdev)
         dist.all_reduce(t)
         bit_errors = int(t.item())
     import math
     sse0 = int(sse[0].item())
     psnr0 = float("inf") if sse0 == 0 else 10 * math.log10(255.0 ** 2 * H * W / sse0)
     gather_ok = None
-    if world > 1 and rank == 0:
+    if use_dist and rank == 0:
         # rank 0's own slice of the gathered stream must be what it extracted
-        gather_ok = bool(torch.equal(gathered[0], extracted[:nbytes]))
+        gather_ok = bool(torch.equal(gathered[last][0].to(dev), extracted[:nbytes]))
 
     result = None
     if rank == 0:
@@ -170,7 +208,7 @@ def main():
             "metric": "Mpixels/sec embed+extract round-trip at 4K; payload bit-error rate (must be 0)",
             "value": mpix_s, "unit": "Mpix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic" + (" (gloo rehearsal - not a result)" if args.rehearse_gloo else ""),
             "config": {"workload": f"{W}x{H} x {F} frames per GPU, {n_ac} AC coeffs/block, delta={delta:g}, "
                                    f"full-capacity payload ({cap} bits per GPU), gray planes resident in HBM",
                        "frames_per_gpu": F, "height": H, "width": W, "n_ac": n_ac, "delta": delta,
@@ -218,7 +256,7 @@ def main():
 
     if rank == 0:
         print(json.dumps(result))
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0 and bit_errors != 0 and delta >= 8:
