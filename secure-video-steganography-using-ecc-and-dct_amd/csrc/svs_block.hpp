@@ -166,13 +166,44 @@ SVS_HD void forward_rows(const uint32_t (&rx)[8], const uint32_t (&ry)[8], float
     for (int u = 0; u < U; ++u) fdct8<8>(V[u], D[u]);
 }
 
-// q = int(round(c / delta)) : float32 division, round half to even (config_and_setup.py:148,160)
-SVS_HD int quant_index(float c, float delta_f) { return (int)rintf(c / delta_f); }
-
 struct QimParams {
-    float delta_f;   // (float)delta  - divisor
-    double delta_d;  // delta         - multiplier when (double)delta_f != delta
+    float delta_f;      // (float)delta  - divisor
+    float inv_delta_f;  // 1 / delta_f   - exact when delta is a power of two (QM_POW2)
+    double delta_d;     // delta         - multiplier when (double)delta_f != delta (QM_DOUBLE)
 };
+
+// How the quantiser is evaluated (all three give the reference's result, they differ in cost):
+//   QM_F32    general delta: IEEE float32 division (about 10 instructions), float32 requantisation
+//   QM_DOUBLE delta not representable in float32 (e.g. 0.1): divide by (float)delta, requantise with
+//             a double multiply rounded once to float32 - what `float(q * delta)` does (:156)
+//   QM_POW2   delta = 2^k: c / delta == c * (1/delta) exactly (both are the correctly rounded value of
+//             the same real number), so the division is one multiply
+enum QuantMode { QM_F32 = 0, QM_DOUBLE = 1, QM_POW2 = 2 };
+
+// q = int(round(c / delta)) : float32 division, round half to even (config_and_setup.py:148,160).
+// General delta: t = c * (1/delta) is within 3 * 2^-24 |t| of the correctly rounded quotient e = fl(c/delta),
+// so rint(t) == rint(e) unless a half-integer lies within that distance of t; only then (about one
+// coefficient in 10^5) is the 10-instruction IEEE division evaluated.  tests/test_block_arithmetic_cpu.py
+// checks the shortcut against the division on 10^8 samples including every exact tie.
+template <int QM>
+SVS_HD int quant_index(float c, const QimParams &qp) {
+#if defined(SVS_QUANT_ALWAYS_DIVIDE)  // A/B build: the plain division everywhere
+    return (int)rintf(c / qp.delta_f);
+#endif
+    if constexpr (QM == QM_POW2) {
+        return (int)rintf(c * qp.inv_delta_f);
+    } else {
+        const float t = c * qp.inv_delta_f;
+        float r = rintf(t);
+        const float miss = fabsf(fabsf(t - r) - 0.5f);       // distance of t from the nearest half-integer
+        if (miss <= fabsf(t) * 4.76837158203125e-7f)          // 2^-21 |t|: comfortably above 3 * 2^-24 |t|
+            r = rintf(c / qp.delta_f);
+        return (int)r;
+    }
+}
+
+// reference form of the above, used by the tests to validate the shortcut
+SVS_HD int quant_index_by_division(float c, float delta_f) { return (int)rintf(c / delta_f); }
 
 // 64 stream bits starting at stream bit s of an MSB-first packed buffer viewed as dwords
 // (touches at most dwords s/32 .. s/32+2, each only if below n_words)
@@ -200,7 +231,7 @@ SVS_HD uint32_t block_budget(uint64_t first, uint64_t n_bits, uint32_t n) {
 }
 
 // Embed `nb` (0..n) payload bits, taken MSB-first from hi:lo, into the block held in rx[]/ry[].
-template <int U, bool DBL>
+template <int U, int QM>
 SVS_HD void embed_block(uint32_t (&rx)[8], uint32_t (&ry)[8], uint32_t n, uint32_t nb, uint32_t hi, uint32_t lo,
                         const QimParams &qp) {
     float D[U][8];
@@ -216,10 +247,10 @@ SVS_HD void embed_block(uint32_t (&rx)[8], uint32_t (&ry)[8], uint32_t n, uint32
             const int i = k - 1;
             const int bit = (int)window_bit(hi, lo, i);
             const float c = D[u][v];
-            int q = quant_index(c, qp.delta_f);
+            int q = quant_index<QM>(c, qp);
             q += bit - (q & 1);  // parity of a negative q is non-negative in python (:150)
             float cn;
-            if constexpr (DBL) cn = (float)((double)q * qp.delta_d);
+            if constexpr (QM == QM_DOUBLE) cn = (float)((double)q * qp.delta_d);
             else cn = (float)q * qp.delta_f;
             change = ((uint32_t)i < nb) ? cn - c : 0.0f;
         }
@@ -249,9 +280,9 @@ SVS_HD void embed_block(uint32_t (&rx)[8], uint32_t (&ry)[8], uint32_t n, uint32
 }
 
 // Parity bits of round(c_k/delta), k = 1..n, MSB-first into hi:lo (config_and_setup.py:160-161)
-template <int U>
-SVS_HD void extract_block(const uint32_t (&rx)[8], const uint32_t (&ry)[8], uint32_t n, float delta_f, uint32_t &hi,
-                          uint32_t &lo) {
+template <int U, int QM>
+SVS_HD void extract_block(const uint32_t (&rx)[8], const uint32_t (&ry)[8], uint32_t n, const QimParams &qp,
+                          uint32_t &hi, uint32_t &lo) {
     float D[U][8];
     forward_rows<U>(rx, ry, D);
     hi = 0;
@@ -259,7 +290,7 @@ SVS_HD void extract_block(const uint32_t (&rx)[8], const uint32_t (&ry)[8], uint
 #pragma unroll
     for (int k = 1; k < 8 * U; ++k) {
         if ((uint32_t)k <= n) {  // wave-uniform
-            const uint32_t bit = (uint32_t)quant_index(D[k >> 3][k & 7], delta_f) & 1u;
+            const uint32_t bit = (uint32_t)quant_index<QM>(D[k >> 3][k & 7], qp) & 1u;
             const int i = k - 1;
             if (i < 32) hi |= bit << ((31 - i) & 31);
             else lo |= bit << ((63 - i) & 31);

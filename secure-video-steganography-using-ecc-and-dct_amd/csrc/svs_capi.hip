@@ -5,6 +5,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -100,6 +101,17 @@ bool rows_allow_two_blocks(const svs_planes *p, const void *a, const void *b) {
            ((uintptr_t)a % 16 == 0) && (b == nullptr || (uintptr_t)b % 16 == 0);
 }
 
+// quantiser parameters and the cheapest exact evaluation mode for this delta (svs::QuantMode)
+int make_qim(double delta, svs::QimParams *qp) {
+    qp->delta_f = (float)delta;
+    qp->inv_delta_f = 1.0f / qp->delta_f;
+    qp->delta_d = delta;
+    if ((double)qp->delta_f != delta) return svs::QM_DOUBLE;
+    int e = 0;
+    const bool pow2 = std::frexp(delta, &e) == 0.5 && e > -100 && e < 100;
+    return pow2 ? svs::QM_POW2 : svs::QM_F32;
+}
+
 struct Tuning {
     bool two_blocks;
     uint32_t chunk;
@@ -107,7 +119,7 @@ struct Tuning {
 
 Tuning embed_tuning(int rows, const svs_planes *p, const void *a, const void *b) {
     Tuning t{rows == 1, kEighth};
-    t.two_blocks = env_chunk("SVS_EMBED_BPL", t.two_blocks ? 2 : 1) == 2;
+    t.two_blocks = rows == 1 && env_chunk("SVS_EMBED_BPL", t.two_blocks ? 2 : 1) == 2;
     t.chunk = env_chunk("SVS_EMBED_XCD_CHUNK", t.chunk);
     t.two_blocks = t.two_blocks && rows_allow_two_blocks(p, a, b);
     return t;
@@ -115,42 +127,56 @@ Tuning embed_tuning(int rows, const svs_planes *p, const void *a, const void *b)
 
 Tuning extract_tuning(int rows, const svs_planes *p, const void *a) {
     Tuning t{false, rows == 1 ? 32u : kEighth};
-    t.two_blocks = env_chunk("SVS_EXTRACT_BPL", 1) == 2;
+    t.two_blocks = rows == 1 && env_chunk("SVS_EXTRACT_BPL", 1) == 2;
     t.chunk = env_chunk("SVS_EXTRACT_XCD_CHUNK", t.chunk);
     t.two_blocks = t.two_blocks && rows_allow_two_blocks(p, a, nullptr);
     return t;
 }
 
-template <bool DBL, int BPL>
+template <int QM, int BPL>
 int launch_embed(int rows, uint64_t total, hipStream_t st, const uint8_t *gray, uint8_t *stego, const svs::Geometry &g,
                  const svs::QimParams &qp, const uint32_t *bits, uint64_t bit_offset, uint64_t n_bits,
                  uint32_t n_words) {
     const dim3 grid((uint32_t)((total + SVS_WG * BPL - 1) / (SVS_WG * BPL)));
 #define SVS_CASE(R)                                                                                            \
     case R:                                                                                                    \
-        hipLaunchKernelGGL((svs::embed_kernel<R, DBL, BPL>), grid, dim3(SVS_WG), 0, st, gray, stego, g, qp, bits, \
+        hipLaunchKernelGGL((svs::embed_kernel<R, QM, BPL>), grid, dim3(SVS_WG), 0, st, gray, stego, g, qp, bits, \
                            bit_offset, n_bits, n_words);                                                       \
         break;
-    switch (rows) {
-        SVS_CASE(1) SVS_CASE(2) SVS_CASE(3) SVS_CASE(4) SVS_CASE(5) SVS_CASE(6) SVS_CASE(7) SVS_CASE(8)
-        default: return fail(SVS_ERR_INVALID_ARG, "internal: rows=%d", rows);
+    if constexpr (BPL == 2) {  // two blocks per lane is only instantiated (and only pays) for one coefficient row
+        switch (rows) {
+            SVS_CASE(1)
+            default: return fail(SVS_ERR_INVALID_ARG, "internal: rows=%d with two blocks per lane", rows);
+        }
+    } else {
+        switch (rows) {
+            SVS_CASE(1) SVS_CASE(2) SVS_CASE(3) SVS_CASE(4) SVS_CASE(5) SVS_CASE(6) SVS_CASE(7) SVS_CASE(8)
+            default: return fail(SVS_ERR_INVALID_ARG, "internal: rows=%d", rows);
+        }
     }
 #undef SVS_CASE
     SVS_HIP(hipGetLastError());
     return SVS_OK;
 }
 
-template <int BPL>
+template <int QM, int BPL>
 int launch_extract(int rows, uint64_t total, hipStream_t st, const uint8_t *gray, const svs::Geometry &g,
-                   float delta_f, uint8_t *out, uint64_t out_bytes) {
+                   const svs::QimParams &qp, uint8_t *out, uint64_t out_bytes) {
     const dim3 grid((uint32_t)((total + SVS_WG * BPL - 1) / (SVS_WG * BPL)));
 #define SVS_CASE(R)                                                                                                  \
     case R:                                                                                                          \
-        hipLaunchKernelGGL((svs::extract_kernel<R, BPL>), grid, dim3(SVS_WG), 0, st, gray, g, delta_f, out, out_bytes); \
+        hipLaunchKernelGGL((svs::extract_kernel<R, QM, BPL>), grid, dim3(SVS_WG), 0, st, gray, g, qp, out, out_bytes); \
         break;
-    switch (rows) {
-        SVS_CASE(1) SVS_CASE(2) SVS_CASE(3) SVS_CASE(4) SVS_CASE(5) SVS_CASE(6) SVS_CASE(7) SVS_CASE(8)
-        default: return fail(SVS_ERR_INVALID_ARG, "internal: rows=%d", rows);
+    if constexpr (BPL == 2) {  // two blocks per lane is only instantiated (and only pays) for one coefficient row
+        switch (rows) {
+            SVS_CASE(1)
+            default: return fail(SVS_ERR_INVALID_ARG, "internal: rows=%d with two blocks per lane", rows);
+        }
+    } else {
+        switch (rows) {
+            SVS_CASE(1) SVS_CASE(2) SVS_CASE(3) SVS_CASE(4) SVS_CASE(5) SVS_CASE(6) SVS_CASE(7) SVS_CASE(8)
+            default: return fail(SVS_ERR_INVALID_ARG, "internal: rows=%d", rows);
+        }
     }
 #undef SVS_CASE
     SVS_HIP(hipGetLastError());
@@ -268,28 +294,27 @@ int svs_embed_dev(const uint8_t *d_gray, uint8_t *d_stego, const svs_planes *pla
     const bool two = tune.two_blocks;
     g.xcd_chunk = tune.chunk;
     svs::QimParams qp;
-    qp.delta_f = (float)delta;
-    qp.delta_d = delta;
+    const int qm = make_qim(use == 0 ? 1.0 : delta, &qp);
     if (use == 0) {
         // pure copy: every block is "past the budget"
         if (d_gray == d_stego) return SVS_OK;
         g.n_ac = 1;
-        qp.delta_f = 1.0f;
-        qp.delta_d = 1.0;
-        return two ? launch_embed<false, 2>(1, total, st, d_gray, d_stego, g, qp, nullptr, 0, 0, 0)
-                   : launch_embed<false, 1>(1, total, st, d_gray, d_stego, g, qp, nullptr, 0, 0, 0);
+        return two ? launch_embed<svs::QM_F32, 2>(1, total, st, d_gray, d_stego, g, qp, nullptr, 0, 0, 0)
+                   : launch_embed<svs::QM_F32, 1>(1, total, st, d_gray, d_stego, g, qp, nullptr, 0, 0, 0);
     }
     const uint64_t last_byte = (bit_offset + use + 7) / 8;
     const uint64_t words = (last_byte + 3) / 4;
     if (words >= (1ull << 32)) return fail(SVS_ERR_INVALID_ARG, "payload too large for one call");
-    const bool dbl = (double)qp.delta_f != delta;
     const uint32_t *bw = reinterpret_cast<const uint32_t *>(d_bits_packed);
     const int rows = rows_for(n);
     int rc;
-    if (dbl) rc = two ? launch_embed<true, 2>(rows, total, st, d_gray, d_stego, g, qp, bw, bit_offset, use, (uint32_t)words)
-                      : launch_embed<true, 1>(rows, total, st, d_gray, d_stego, g, qp, bw, bit_offset, use, (uint32_t)words);
-    else rc = two ? launch_embed<false, 2>(rows, total, st, d_gray, d_stego, g, qp, bw, bit_offset, use, (uint32_t)words)
-                  : launch_embed<false, 1>(rows, total, st, d_gray, d_stego, g, qp, bw, bit_offset, use, (uint32_t)words);
+#define SVS_GO(QM)                                                                                                   \
+    rc = two ? launch_embed<QM, 2>(rows, total, st, d_gray, d_stego, g, qp, bw, bit_offset, use, (uint32_t)words)   \
+             : launch_embed<QM, 1>(rows, total, st, d_gray, d_stego, g, qp, bw, bit_offset, use, (uint32_t)words)
+    if (qm == svs::QM_DOUBLE) SVS_GO(svs::QM_DOUBLE);
+    else if (qm == svs::QM_POW2) SVS_GO(svs::QM_POW2);
+    else SVS_GO(svs::QM_F32);
+#undef SVS_GO
     if (rc) return rc;
     if (n_embedded) *n_embedded = use;
     return SVS_OK;
@@ -317,9 +342,16 @@ int svs_extract_dev(const uint8_t *d_gray, const svs_planes *planes, double delt
     } else {
         const Tuning tune = extract_tuning(rows_for(n), planes, d_gray);
         g.xcd_chunk = tune.chunk;
-        const int rc = tune.two_blocks
-                           ? launch_extract<2>(rows_for(n), total, st, d_gray, g, (float)delta, d_bits_packed_out, bytes)
-                           : launch_extract<1>(rows_for(n), total, st, d_gray, g, (float)delta, d_bits_packed_out, bytes);
+        svs::QimParams qp;
+        const int qm = make_qim(delta, &qp);     // the double mode only differs in requantisation: not needed here
+        const int rows = rows_for(n);
+        int rc;
+        if (qm == svs::QM_POW2)
+            rc = tune.two_blocks ? launch_extract<svs::QM_POW2, 2>(rows, total, st, d_gray, g, qp, d_bits_packed_out, bytes)
+                                 : launch_extract<svs::QM_POW2, 1>(rows, total, st, d_gray, g, qp, d_bits_packed_out, bytes);
+        else
+            rc = tune.two_blocks ? launch_extract<svs::QM_F32, 2>(rows, total, st, d_gray, g, qp, d_bits_packed_out, bytes)
+                                 : launch_extract<svs::QM_F32, 1>(rows, total, st, d_gray, g, qp, d_bits_packed_out, bytes);
         if (rc) return rc;
     }
     if (n_bits_out) *n_bits_out = cap;

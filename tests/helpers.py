@@ -95,6 +95,8 @@ def hostemu():
                                 ctypes.c_int, ctypes.c_void_p]
     lib.emu_forward_block.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
     lib.emu_idct8.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    lib.emu_quant_mismatches.restype = ctypes.c_uint64
+    lib.emu_quant_mismatches.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_double]
     _EMU = lib
     return lib
 

@@ -5,12 +5,23 @@
 // it against the oracle without a GPU.  The lane/wave mapping, HBM access and LDS bit packing of
 // the kernels are NOT modelled here; those are covered by the -m gpu tests.
 // Build: g++ -O2 -ffp-contract=off -std=c++17 -shared -fPIC -I<csrc> hostemu.cpp -o libsvs_hostemu.so
+#include <cmath>
 #include <cstdint>
 #include <cstring>
 
 #include "svs_block.hpp"
 
 namespace {
+
+// same mode selection as make_qim() in csrc/svs_capi.hip
+int make_qim(double delta, svs::QimParams *qp) {
+    qp->delta_f = (float)delta;
+    qp->inv_delta_f = 1.0f / qp->delta_f;
+    qp->delta_d = delta;
+    if ((double)qp->delta_f != delta) return svs::QM_DOUBLE;
+    int e = 0;
+    return std::frexp(delta, &e) == 0.5 ? svs::QM_POW2 : svs::QM_F32;
+}
 
 struct Blk {
     uint32_t x[8], y[8];
@@ -29,13 +40,14 @@ struct Blk {
 };
 
 template <int U>
-void embed_u(Blk &raw, uint32_t n, uint32_t nb, uint32_t hi, uint32_t lo, const svs::QimParams &qp, bool dbl) {
-    if (dbl) svs::embed_block<U, true>(raw.x, raw.y, n, nb, hi, lo, qp);
-    else svs::embed_block<U, false>(raw.x, raw.y, n, nb, hi, lo, qp);
+void embed_u(Blk &raw, uint32_t n, uint32_t nb, uint32_t hi, uint32_t lo, const svs::QimParams &qp, int qm) {
+    if (qm == svs::QM_DOUBLE) svs::embed_block<U, svs::QM_DOUBLE>(raw.x, raw.y, n, nb, hi, lo, qp);
+    else if (qm == svs::QM_POW2) svs::embed_block<U, svs::QM_POW2>(raw.x, raw.y, n, nb, hi, lo, qp);
+    else svs::embed_block<U, svs::QM_F32>(raw.x, raw.y, n, nb, hi, lo, qp);
 }
 
 void embed_dispatch(int rows, Blk &raw, uint32_t n, uint32_t nb, uint32_t hi, uint32_t lo,
-                    const svs::QimParams &qp, bool dbl) {
+                    const svs::QimParams &qp, int dbl) {
     switch (rows) {
         case 1: embed_u<1>(raw, n, nb, hi, lo, qp, dbl); break;
         case 2: embed_u<2>(raw, n, nb, hi, lo, qp, dbl); break;
@@ -48,16 +60,17 @@ void embed_dispatch(int rows, Blk &raw, uint32_t n, uint32_t nb, uint32_t hi, ui
     }
 }
 
-void extract_dispatch(int rows, const Blk &raw, uint32_t n, float d, uint32_t &hi, uint32_t &lo) {
+template <int QM>
+void extract_dispatch(int rows, const Blk &raw, uint32_t n, const svs::QimParams &d, uint32_t &hi, uint32_t &lo) {
     switch (rows) {
-        case 1: svs::extract_block<1>(raw.x, raw.y, n, d, hi, lo); break;
-        case 2: svs::extract_block<2>(raw.x, raw.y, n, d, hi, lo); break;
-        case 3: svs::extract_block<3>(raw.x, raw.y, n, d, hi, lo); break;
-        case 4: svs::extract_block<4>(raw.x, raw.y, n, d, hi, lo); break;
-        case 5: svs::extract_block<5>(raw.x, raw.y, n, d, hi, lo); break;
-        case 6: svs::extract_block<6>(raw.x, raw.y, n, d, hi, lo); break;
-        case 7: svs::extract_block<7>(raw.x, raw.y, n, d, hi, lo); break;
-        default: svs::extract_block<8>(raw.x, raw.y, n, d, hi, lo); break;
+        case 1: svs::extract_block<1, QM>(raw.x, raw.y, n, d, hi, lo); break;
+        case 2: svs::extract_block<2, QM>(raw.x, raw.y, n, d, hi, lo); break;
+        case 3: svs::extract_block<3, QM>(raw.x, raw.y, n, d, hi, lo); break;
+        case 4: svs::extract_block<4, QM>(raw.x, raw.y, n, d, hi, lo); break;
+        case 5: svs::extract_block<5, QM>(raw.x, raw.y, n, d, hi, lo); break;
+        case 6: svs::extract_block<6, QM>(raw.x, raw.y, n, d, hi, lo); break;
+        case 7: svs::extract_block<7, QM>(raw.x, raw.y, n, d, hi, lo); break;
+        default: svs::extract_block<8, QM>(raw.x, raw.y, n, d, hi, lo); break;
     }
 }
 
@@ -74,8 +87,8 @@ uint64_t emu_embed(const uint8_t *gray, uint8_t *stego, int F, int H, int W, dou
     uint64_t use = n_bits < total * n ? n_bits : total * n;
     if (!(delta > 0.0) || n == 0) use = 0;
     if (use == 0) return 0;
-    svs::QimParams qp{(float)delta, delta};
-    const bool dbl = (double)qp.delta_f != delta;
+    svs::QimParams qp;
+    const int dbl = make_qim(delta, &qp);
     const uint32_t n_words = (uint32_t)(bits_bytes / 4);
     for (uint64_t gb = 0; gb < total; ++gb) {
         const uint64_t first = gb * n;
@@ -103,6 +116,8 @@ uint64_t emu_extract(const uint8_t *gray, int F, int H, int W, double delta, int
         std::memset(out_flags, 0, total * n);
         return total * n;
     }
+    svs::QimParams qp;
+    const int qm = make_qim(delta, &qp);
     for (uint64_t gb = 0; gb < total; ++gb) {
         const uint64_t f = gb / bpf, b = gb % bpf;
         const uint64_t by = b / (W / 8), bx = b % (W / 8);
@@ -110,7 +125,8 @@ uint64_t emu_extract(const uint8_t *gray, int F, int H, int W, double delta, int
         Blk raw;
         raw.load(p, (size_t)W);
         uint32_t hi, lo;
-        extract_dispatch(svs::rows_for(n), raw, (uint32_t)n, (float)delta, hi, lo);
+        if (qm == svs::QM_POW2) extract_dispatch<svs::QM_POW2>(svs::rows_for(n), raw, (uint32_t)n, qp, hi, lo);
+        else extract_dispatch<svs::QM_F32>(svs::rows_for(n), raw, (uint32_t)n, qp, hi, lo);
         for (int i = 0; i < n; ++i) out_flags[gb * n + i] = (uint8_t)svs::window_bit(hi, lo, i);
     }
     return total * n;
@@ -123,6 +139,16 @@ void emu_forward_block(const uint8_t *block64, float *D64) {
     float D[8][8];
     svs::forward_rows<8>(raw.x, raw.y, D);
     std::memcpy(D64, D, sizeof D);
+}
+
+// number of (c, delta) pairs on which the reciprocal-multiply quantiser differs from the IEEE division
+uint64_t emu_quant_mismatches(const float *c, uint64_t n, double delta) {
+    svs::QimParams qp;
+    make_qim(delta, &qp);
+    uint64_t bad = 0;
+    for (uint64_t i = 0; i < n; ++i)
+        bad += svs::quant_index<svs::QM_F32>(c[i], qp) != svs::quant_index_by_division(c[i], qp.delta_f);
+    return bad;
 }
 
 void emu_idct8(const float *X, float *x) {

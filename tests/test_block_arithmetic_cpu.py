@@ -29,6 +29,28 @@ def test_forward_and_inverse_transform_accuracy():
         assert np.abs(out - idct(vec.astype(np.float64), norm="ortho")).max() < 1e-4
 
 
+def test_reciprocal_quantiser_equals_ieee_division():
+    """quant_index<QM_F32> replaces c/delta by c*(1/delta) with an exact-division fallback near rounding
+    ties; it must give the division's result for every input, exact ties (k + 1/2) included."""
+    lib = hostemu()
+    rng = np.random.default_rng(5)
+    total = 0
+    for delta in [20, 1, 3, 7, 7.5, 9, 10, 12, 20.0, 25, 33, 100, 0.3, 1e-3, 1000, float(np.float32(6.1))]:
+        d32 = float(np.float32(delta))
+        if d32 != delta:
+            continue                                   # non-representable deltas use the double mode
+        parts = [rng.uniform(-2100, 2100, 2_000_000).astype(np.float32),
+                 (rng.integers(-16320, 16321, 1_000_000) / 8.0).astype(np.float32)]       # exact multiples of 1/8
+        k = np.arange(-3000, 3000, dtype=np.float64)
+        ties = ((k + 0.5) * delta).astype(np.float32)                                     # c/delta exactly k + 1/2 ...
+        parts += [ties, np.nextafter(ties, np.float32(np.inf)), np.nextafter(ties, np.float32(-np.inf))]
+        parts += [np.float32([0.0, -0.0, 1e-30, -1e-30, 1e-45, 3e38, -3e38])]
+        c = np.ascontiguousarray(np.concatenate(parts))
+        assert lib.emu_quant_mismatches(c.ctypes.data, c.size, float(delta)) == 0, delta
+        total += c.size
+    assert total > 3e7
+
+
 def test_golden_vectors(golden):
     arrays, meta = golden
     for name in single_frame_cases(meta):
