@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 from scipy.fftpack import dct, idct
 
-from helpers import (NOISE_ONLY_CASES, case_inputs, emu_embed, emu_extract, exact_tie_mask, golden_bits,
+from testlib import (NOISE_ONLY_CASES, case_inputs, emu_embed, emu_extract, exact_tie_mask, golden_bits,
                      hostemu, single_frame_cases)
 from oracle import qim_dct_oracle as orc
 from svsdct import synth

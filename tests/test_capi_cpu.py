@@ -7,7 +7,7 @@ import re
 import numpy as np
 import pytest
 
-from helpers import REPO
+from testlib import REPO
 from svsdct import batch, native, synth
 
 

@@ -13,7 +13,7 @@ import os
 import numpy as np
 import pytest
 
-from helpers import (NOISE_ONLY_CASES, REPO, case_inputs, emu_embed, emu_extract, exact_tie_mask, golden_bits,
+from testlib import (NOISE_ONLY_CASES, REPO, case_inputs, emu_embed, emu_extract, exact_tie_mask, golden_bits,
                      single_frame_cases)
 from oracle import qim_dct_oracle as orc
 from svsdct import batch, native, synth

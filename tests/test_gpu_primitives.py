@@ -6,7 +6,7 @@ import os
 import numpy as np
 import pytest
 
-from helpers import REPO
+from testlib import REPO
 from svsdct import native
 
 pytestmark = pytest.mark.gpu

@@ -1,0 +1,194 @@
+"""The drop-in video pipelines (`embed_gambar_ke_video_final`, `ekstraksi_gambar_video_final`): frame
+loops, bit-offset bookkeeping, payload framing, "copy the remaining frames in colour", failure exits.
+
+cv2 and cryptography are absent from the build image, so tests/fakes.py stands in for them (in-memory
+videos, stand-in cipher with the same call shapes).  The frame operator itself is
+  * the CPU build of the kernel header (tests/hostemu) in the CPU tier - frame-loop logic only;
+  * the real HIP kernels in the -m gpu tier.
+"""
+import sys
+
+import numpy as np
+import pytest
+from PIL import Image
+
+import fakes
+from testlib import emu_embed, emu_extract
+from oracle import qim_dct_oracle as orc
+from svsdct import batch, framing, synth
+
+
+def _install(monkeypatch, backend):
+    monkeypatch.setitem(sys.modules, "cv2", fakes.make_fake_cv2())
+    import embed_process
+    import extract_process
+    for mod in (embed_process, extract_process):
+        for name in fakes.CRYPTO_NAMES:
+            if hasattr(mod, name):
+                monkeypatch.setattr(mod, name, getattr(fakes, name))
+    if backend == "emu":
+        def embed_frames(frames, delta, n_ac, bits, bit_offset=0, n_bits=None, device=0):
+            bits = np.asarray(bits, np.uint8)
+            n_bits = bits.size - bit_offset if n_bits is None else n_bits
+            return emu_embed(np.asarray(frames), delta, n_ac, bits[:bit_offset + n_bits], bit_offset)
+
+        def extract_frames(frames, delta, n_ac, device=0):
+            flags = emu_extract(np.asarray(frames), delta, n_ac)
+            return np.packbits(flags), int(flags.size)
+        monkeypatch.setattr(batch, "embed_frames", embed_frames)
+        monkeypatch.setattr(batch, "extract_frames", extract_frames)
+    fakes.VIDEOS.clear()
+    return embed_process, extract_process
+
+
+def _make_inputs(tmp_path, n_frames=6, size=(75, 100), secret=(8, 8), seed=4):
+    rng = np.random.default_rng(seed)
+    h, w = size
+    frames = [np.stack([synth.synthetic_frames(1, h, w, seed=seed + 10 * c, first_frame=k)[0] for c in range(3)], -1)
+              for k in range(n_frames)]
+    fakes.VIDEOS["in.mp4"] = {"frames": frames, "fps": 24.0}
+    img = rng.integers(0, 256, (secret[1], secret[0]), dtype=np.uint8)
+    path = str(tmp_path / "secret.png")
+    Image.fromarray(img, mode="L").save(path)
+    return frames, img, path
+
+
+BACKENDS = ["emu", pytest.param("gpu", marks=pytest.mark.gpu)]
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_round_trip_through_both_pipelines(monkeypatch, tmp_path, capsys, backend):
+    emb, ext = _install(monkeypatch, backend)
+    frames, secret, secret_path = _make_inputs(tmp_path)
+    receiver = fakes.FakeKey(b"bob")
+    pub = fakes.serialisasi_kunci_publik_ecc_compressed(receiver.public())
+    delta, n_ac = 20, 10
+
+    ok, g0, s0 = emb.embed_gambar_ke_video_final("in.mp4", secret_path, str(tmp_path / "stego.mp4"), delta, n_ac, pub)
+    assert ok is True
+    out = fakes.VIDEOS[str(tmp_path / "stego.avi")]                     # extension forced to .avi, FFV1
+    assert out["fourcc"] == sum(ord(c) << (8 * i) for i, c in enumerate("FFV1")) and out["size"] == (96, 72)
+    assert len(out["frames"]) == len(frames)
+
+    cv2 = sys.modules["cv2"]
+    per_frame = 9 * 12 * n_ac
+    total = framing.HEADER_BITS_STANDARD + 8 * secret.size            # 976 + 512
+    carrying = -(-total // per_frame)                                   # 2 frames
+    log = capsys.readouterr().out
+    assert f"Frame 1: {per_frame} bits disisipkan. Total disisipkan: {per_frame}/{total}" in log
+    assert f"Frame 2: {total - per_frame} bits disisipkan. Total disisipkan: {total}/{total}" in log
+    gray_in = [cv2.cvtColor(f[:72, :96], cv2.COLOR_BGR2GRAY) for f in frames]
+    assert np.array_equal(g0, gray_in[0])
+    for k, f in enumerate(out["frames"]):
+        if k < carrying:                                                # stego frames are gray, replicated
+            assert (f[..., 0] == f[..., 1]).all() and (f[..., 1] == f[..., 2]).all()
+        else:                                                           # the rest: cropped colour copies
+            assert np.array_equal(f, frames[k][:72, :96])
+    assert np.array_equal(s0, out["frames"][0][..., 0])
+
+    # the stego frames are those a frame-by-frame loop over the reference operator produces: same
+    # extracted bits; same PSNR up to the exact-tie blocks of SURVEY N6 (n = 10 includes flat index 4; one
+    # such block moves the PSNR of this 108-block frame by ~0.01 dB, hence the wider bound than at real sizes)
+    stream = orc.batch_extract_bits(np.stack([f[..., 0] for f in out["frames"][:carrying]]), delta, n_ac)
+    hdr = framing.parse_header(stream)
+    assert (hdr.width, hdr.height, hdr.ciphertext_len, hdr.bits) == (8, 8, 64, 976)
+    ref, used = orc.batch_embed(np.stack(gray_in[:carrying]), delta, stream[:total], n_ac)
+    assert used == total
+    for k in range(carrying):
+        assert abs(orc.psnr_u8(gray_in[k], out["frames"][k][..., 0]) - orc.psnr_u8(gray_in[k], ref[k])) <= 0.05
+        differing = (out["frames"][k][..., 0] != ref[k]).reshape(9, 8, 12, 8).any(axis=(1, 3)).sum()
+        assert differing <= 3
+
+    ok = ext.ekstraksi_gambar_video_final(str(tmp_path / "stego.avi"), str(tmp_path / "out.png"), delta, n_ac, receiver)
+    assert ok is True
+    assert np.array_equal(np.asarray(Image.open(str(tmp_path / "out.png"))), secret)
+    log = capsys.readouterr().out
+    assert "Verifikasi Hash SHA3-256 BERHASIL" in log and "Melanjutkan ke frame berikutnya" in log
+
+    # wrong receiver key -> authentication fails -> False, nothing written
+    assert ext.ekstraksi_gambar_video_final(str(tmp_path / "stego.avi"), str(tmp_path / "bad.png"), delta, n_ac,
+                                            fakes.FakeKey(b"eve")) is False
+    # wrong delta -> garbage header -> False (never raises)
+    assert ext.ekstraksi_gambar_video_final(str(tmp_path / "stego.avi"), str(tmp_path / "bad.png"), 7, n_ac,
+                                            receiver) is False
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_payload_spread_over_many_frames_and_batches(monkeypatch, tmp_path, backend):
+    emb, ext = _install(monkeypatch, backend)
+    monkeypatch.setattr(emb, "BATCH_FRAMES", 3)
+    monkeypatch.setattr(ext, "BATCH_FRAMES", 2)
+    frames, secret, secret_path = _make_inputs(tmp_path, n_frames=12, size=(32, 48), secret=(16, 12), seed=9)
+    receiver = fakes.FakeKey(b"bob")
+    pub = fakes.serialisasi_kunci_publik_ecc_compressed(receiver.public())
+    delta, n_ac = 12, 15                                                # 24 blocks * 15 = 360 bits per frame
+    ok, _, _ = emb.embed_gambar_ke_video_final("in.mp4", secret_path, str(tmp_path / "s"), delta, n_ac, pub)
+    assert ok                                                           # 976 + 1536 = 2512 bits -> 7 frames
+    out = fakes.VIDEOS[str(tmp_path / "s.avi")]["frames"]
+    assert np.array_equal(out[7], frames[7]) and not np.array_equal(out[6], frames[6])
+    assert ext.ekstraksi_gambar_video_final(str(tmp_path / "s.avi"), str(tmp_path / "o.png"), delta, n_ac, receiver)
+    assert np.array_equal(np.asarray(Image.open(str(tmp_path / "o.png"))), secret)
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_failure_exits(monkeypatch, tmp_path, capsys, backend):
+    emb, ext = _install(monkeypatch, backend)
+    frames, secret, secret_path = _make_inputs(tmp_path, n_frames=1, size=(72, 96))
+    pub = fakes.serialisasi_kunci_publik_ecc_compressed(fakes.FakeKey(b"bob").public())
+    # video too short for the payload
+    assert emb.embed_gambar_ke_video_final("in.mp4", secret_path, str(tmp_path / "s"), 20, 10, pub) == (False, None, None)
+    assert "Video selesai sebelum semua payload" in capsys.readouterr().out
+    # missing files
+    assert emb.embed_gambar_ke_video_final("nope.mp4", secret_path, str(tmp_path / "s"), 20, 10, pub) == (False, None, None)
+    assert emb.embed_gambar_ke_video_final("in.mp4", str(tmp_path / "nope.png"), str(tmp_path / "s"), 20, 10, pub) == (False, None, None)
+    assert ext.ekstraksi_gambar_video_final("nope.avi", str(tmp_path / "o.png"), 20, 10, fakes.FakeKey(b"bob")) is False
+    # stego video that ends before the header is complete
+    fakes.VIDEOS["tiny.avi"] = {"frames": [np.zeros((16, 16, 3), np.uint8)], "fps": 24.0}
+    assert ext.ekstraksi_gambar_video_final("tiny.avi", str(tmp_path / "o.png"), 20, 3, fakes.FakeKey(b"bob")) is False
+    assert "Video habis sebelum cukup bit diekstrak" in capsys.readouterr().out
+
+
+def test_framing_layout_and_errors():
+    fields = dict(eph_pub=b"\x02" + bytes(range(32)), salt=bytes(16), digest=bytes(range(32)), nonce=bytes(12),
+                  tag=bytes(range(16)), ciphertext=b"\xAA\x55" * 10)
+    bits = framing.build_payload_bits(300, 200, **fields)
+    assert bits.size == 976 + 160 == framing.HEADER_BITS_STANDARD + 160
+    text = "".join(map(str, bits))
+    assert text[:16] == format(300, "016b") and text[16:32] == format(200, "016b")
+    assert text[32:40] == format(33, "08b") and text[40:48] == "00000010"           # length byte, then 0x02
+    assert text[944:976] == format(20, "032b") and text[976:984] == "10101010"
+    hdr = framing.parse_header(bits)
+    assert (hdr.width, hdr.height, hdr.ciphertext_len, hdr.bits) == (300, 200, 20, 976)
+    assert (hdr.eph_pub, hdr.digest, hdr.tag) == (fields["eph_pub"], fields["digest"], fields["tag"])
+    with pytest.raises(framing.HeaderIncomplete) as err:
+        framing.parse_header(bits[:500])
+    assert err.value.needed > 500
+    with pytest.raises(ValueError, match="0x0"):
+        framing.parse_header(np.zeros(1000, np.uint8))
+    with pytest.raises(ValueError):
+        framing.build_payload_bits(70000, 1, **fields)
+
+
+def test_helpers_and_evaluation_modules(tmp_path):
+    import evaluation
+    import helpers as steg
+    img = (np.arange(50 * 30) % 256).astype(np.uint8).reshape(30, 50)          # the reference's self-test shape
+    path = str(tmp_path / "g.png")
+    Image.fromarray(img, mode="L").save(path)
+    w, h, bits = steg.gambar_ke_bitstream(path)
+    assert (w, h, len(bits)) == (50, 30, 50 * 30 * 8) and bits[:8] == format(int(img[0, 0]), "08b")
+    assert np.array_equal(np.asarray(steg.bitstream_ke_gambar(bits, w, h)), img)
+    assert steg.bitstream_ke_gambar(bits[:-8], w, h) is None
+    assert steg.gambar_ke_bitstream(str(tmp_path / "none.png")) == (None, None, None)
+    meta = steg.buat_metadata_bitstream(w, h)
+    assert meta == format(50, "016b") + format(30, "016b") and steg.parse_metadata_bitstream(meta + "111") == (50, 30)
+    with pytest.raises(ValueError):
+        steg.buat_metadata_bitstream(65536, 1)
+    with pytest.raises(ValueError):
+        steg.parse_metadata_bitstream("0101")
+    assert steg.get_avi_path("media/out/stego.mp4") == "media/out/stego.avi"
+    a, b = np.full((8, 8), 100, np.uint8), np.full((8, 8), 110, np.uint8)
+    assert abs(evaluation.psnr(a, b) - 10 * np.log10(255 ** 2 / 100)) < 1e-9
+    assert evaluation.psnr(a, a) == float("inf")
+    # the reference's uint8 quirk: |diff| >= 16 wraps (30*30 = 900 = 132 mod 256)
+    assert abs(evaluation.psnr(a, np.full((8, 8), 130, np.uint8)) - 20 * np.log10(255 / np.sqrt(132))) < 1e-9
