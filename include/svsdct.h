@@ -42,13 +42,25 @@
 extern "C" {
 #endif
 
-#define SVS_ABI_VERSION 1
+#define SVS_ABI_VERSION 2
 
 #define SVS_OK 0
 #define SVS_ERR_INVALID_ARG (-1)  /* bad geometry / NULL pointer / size overflow */
 #define SVS_ERR_HIP (-2)          /* a HIP runtime call failed; see svs_last_error() */
 #define SVS_ERR_NO_DEVICE (-3)    /* no usable AMD GPU */
 #define SVS_ERR_CAPACITY (-4)     /* an output buffer is too small */
+
+/* `flags` of the embed / extract entry points.
+ *   0                  FAST transforms: an FMA-factored float32 DCT restricted to the coefficient rows the
+ *                      payload touches.  Meets the operator's contract - extracted bits bit-exact, stego PSNR
+ *                      within 0.01 dB of the reference - and runs on the HBM roofline.  Stego pixels can differ
+ *                      from the reference's where it resolves an exact rounding tie by float32 noise, and a block
+ *                      that receives no coefficient change is left untouched.
+ *   SVS_EXACT_POCKETFFT  every float32 operation of scipy.fftpack.dct/idct(norm='ortho') (pocketfft) is
+ *                      replayed in order, on all 64 coefficients: stego pixels, tie decisions and the
+ *                      reference's round-trip artefacts (config_and_setup.py:166-171 on untouched blocks) are
+ *                      bit-identical to the reference.  About 2.5x the arithmetic: VALU-bound. */
+#define SVS_EXACT_POCKETFFT 1u
 
 /* Geometry of a batch of gray planes. */
 typedef struct svs_planes {
@@ -94,17 +106,18 @@ uint64_t svs_packed_bytes(uint64_t n_bits);
  *                  Blocks past the budget are copied byte-identically; a block the budget ends
  *                  in has only its first coefficients modified (config_and_setup.py:130,132,141).
  *   n_embedded   : (host) receives min(n_bits, capacity); 0 when delta <= 0 or n_ac <= 0.
- * delta <= 0 or n_ac <= 0: nothing can be embedded; stego = gray (deviations).
+ * delta <= 0 or n_ac <= 0: nothing can be embedded.  FAST: stego = gray.  EXACT: as in the reference, every
+ * block is still transformed forth and back when n_bits > 0 (config_and_setup.py:143-145,166-169).
  */
 int svs_embed_dev(const uint8_t *d_gray, uint8_t *d_stego, const svs_planes *planes,
                   double delta, int n_ac,
                   const uint8_t *d_bits_packed, uint64_t bit_offset, uint64_t n_bits,
-                  uint64_t *n_embedded, void *stream);
+                  uint32_t flags, uint64_t *n_embedded, void *stream);
 
 int svs_embed(const uint8_t *gray, uint8_t *stego, const svs_planes *planes,
               double delta, int n_ac,
               const uint8_t *bits_packed, uint64_t bit_offset, uint64_t n_bits,
-              uint64_t *n_embedded);
+              uint32_t flags, uint64_t *n_embedded);
 
 /* ---- the operator: extract ----------------------------------------------------------------
  * Replaces mode 'extract' (config_and_setup.py:159-165,173-174) for a whole batch and the
@@ -116,10 +129,11 @@ int svs_embed(const uint8_t *gray, uint8_t *stego, const svs_planes *planes,
  */
 int svs_extract_dev(const uint8_t *d_gray, const svs_planes *planes, double delta, int n_ac,
                     uint8_t *d_bits_packed_out, uint64_t out_capacity_bytes,
-                    uint64_t *n_bits_out, void *stream);
+                    uint32_t flags, uint64_t *n_bits_out, void *stream);
 
 int svs_extract(const uint8_t *gray, const svs_planes *planes, double delta, int n_ac,
-                uint8_t *bits_packed_out, uint64_t out_capacity_bytes, uint64_t *n_bits_out);
+                uint8_t *bits_packed_out, uint64_t out_capacity_bytes, uint32_t flags,
+                uint64_t *n_bits_out);
 
 /* ---- measurement helpers (synthetic inputs and on-device checks for bench.py / tests) ------ */
 /* value = lo + hash32(seed, first_frame + f, y, x) % span  - same hash as svsdct/synth.py */

@@ -298,6 +298,235 @@ SVS_HD void extract_block(const uint32_t (&rx)[8], const uint32_t (&ry)[8], uint
     }
 }
 
+// =====================================================================================================
+// EXACT mode: bit-for-bit the float32 arithmetic of scipy.fftpack.dct/idct(norm='ortho') for length 8.
+//
+// scipy's DCT is pocketfft (C++, `T_dcst23<float>::exec`; scipy unpinned in the reference, vectors
+// generated with scipy 1.15.3).  For N = 8 its published algorithm is: DCT-II = pre-butterfly ->
+// BACKWARD real FFT of length 8 (radix passes radb2(ido=4), radb4(ido=1), factors [2,4]) scaled by
+// fct = 1/sqrt(2N) = 0.25 -> twiddle post-pass with cos((k+1)pi/16) -> c[0] *= sqrt(2)/2;  DCT-III is
+// the mirror image with the FORWARD real FFT (radf4(ido=1), radf2(ido=4)).  Every operation below is one
+// IEEE float32 add/sub/mul in pocketfft's order (no FMA: build with -ffp-contract=off), so the results
+// are bit-identical to scipy's - checked on random and integer vectors in tests/test_exact_mode_cpu.py and,
+// through the whole operator, against every golden vector (stego PIXELS included).
+// With these transforms the operator reproduces the reference's rounding-noise artefacts too
+// (SURVEY N4/N6): exact .5 ties, 128 -> 127 on untouched flat blocks, delta <= 0 round trips.
+// =====================================================================================================
+namespace pf {
+// float(cos((i+1) pi / 16)), i = 0..6: pocketfft's `twiddle[i]` for N = 8
+#define SVS_PF_T0 0x1.f6297cp-1f
+#define SVS_PF_T1 0x1.d906bcp-1f
+#define SVS_PF_T2 0x1.a9b662p-1f
+#define SVS_PF_T3 0x1.6a09e6p-1f
+#define SVS_PF_T4 0x1.1c73b4p-1f
+#define SVS_PF_T5 0x1.87de2ap-2f
+#define SVS_PF_T6 0x1.8f8b84p-3f
+#define SVS_PF_W 0x1.6a09e6p-1f      // cos(2pi/8) = sin(2pi/8) as float: the radix-2 pass twiddle
+#define SVS_PF_SQRT2 0x1.6a09e6p+0f  // float(sqrt 2)
+#define SVS_PF_FCT 0.25f             // 1/sqrt(2*8)
+
+// backward real FFT (halfcomplex -> real) of length 8, scaled by fct
+SVS_HD void rfft8_backward(const float (&c)[8], float (&o)[8]) {
+    float h[8];
+    // radb2, ido = 4, l1 = 1
+    h[0] = c[0] + c[7];
+    h[4] = c[0] - c[7];
+    h[3] = 2.0f * c[3];
+    h[7] = -2.0f * c[4];
+    h[1] = c[1] + c[5];
+    const float tr2 = c[1] - c[5];
+    const float ti2 = c[2] + c[6];
+    h[2] = c[2] - c[6];
+    h[6] = SVS_PF_W * ti2 + SVS_PF_W * tr2;
+    h[5] = SVS_PF_W * tr2 - SVS_PF_W * ti2;
+    // radb4, ido = 1, l1 = 2
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const float a = h[4 * k] + h[4 * k + 3], b = h[4 * k] - h[4 * k + 3];
+        const float t3 = 2.0f * h[4 * k + 1], t4 = 2.0f * h[4 * k + 2];
+        o[k] = (a + t3) * SVS_PF_FCT;
+        o[k + 4] = (a - t3) * SVS_PF_FCT;
+        o[k + 6] = (b + t4) * SVS_PF_FCT;
+        o[k + 2] = (b - t4) * SVS_PF_FCT;
+    }
+}
+
+// forward real FFT (real -> halfcomplex) of length 8, scaled by fct
+SVS_HD void rfft8_forward(const float (&c)[8], float (&o)[8]) {
+    float y[8];
+    // radf4, ido = 1, l1 = 2
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const float tr1 = c[k + 6] + c[k + 2];
+        y[4 * k + 2] = c[k + 6] - c[k + 2];
+        const float tr2 = c[k] + c[k + 4];
+        y[4 * k + 1] = c[k] - c[k + 4];
+        y[4 * k] = tr2 + tr1;
+        y[4 * k + 3] = tr2 - tr1;
+    }
+    // radf2, ido = 4, l1 = 1
+    const float tr2 = SVS_PF_W * y[5] + SVS_PF_W * y[6];
+    const float ti2 = SVS_PF_W * y[6] - SVS_PF_W * y[5];
+    o[0] = (y[0] + y[4]) * SVS_PF_FCT;
+    o[7] = (y[0] - y[4]) * SVS_PF_FCT;
+    o[4] = (-y[7]) * SVS_PF_FCT;
+    o[3] = y[3] * SVS_PF_FCT;
+    o[1] = (y[1] + tr2) * SVS_PF_FCT;
+    o[5] = (y[1] - tr2) * SVS_PF_FCT;
+    o[2] = (ti2 + y[2]) * SVS_PF_FCT;
+    o[6] = (ti2 - y[2]) * SVS_PF_FCT;
+}
+
+// scipy.fftpack.dct(x, type=2, norm='ortho') for 8 float32 values
+SVS_HD void dct2_8(const float (&x)[8], float (&X)[8]) {
+    float c[8];
+    c[0] = x[0] * 2.0f;
+    c[7] = x[7] * 2.0f;
+#pragma unroll
+    for (int k = 1; k < 7; k += 2) {  // MPINPLACE(c[k+1], c[k])
+        c[k + 1] = x[k + 1] - x[k];
+        c[k] = x[k] + x[k + 1];
+    }
+    float r[8];
+    rfft8_backward(c, r);
+    {
+        const float t1 = SVS_PF_T0 * r[7] + SVS_PF_T6 * r[1], t2 = SVS_PF_T0 * r[1] - SVS_PF_T6 * r[7];
+        X[1] = 0.5f * (t1 + t2);
+        X[7] = 0.5f * (t1 - t2);
+    }
+    {
+        const float t1 = SVS_PF_T1 * r[6] + SVS_PF_T5 * r[2], t2 = SVS_PF_T1 * r[2] - SVS_PF_T5 * r[6];
+        X[2] = 0.5f * (t1 + t2);
+        X[6] = 0.5f * (t1 - t2);
+    }
+    {
+        const float t1 = SVS_PF_T2 * r[5] + SVS_PF_T4 * r[3], t2 = SVS_PF_T2 * r[3] - SVS_PF_T4 * r[5];
+        X[3] = 0.5f * (t1 + t2);
+        X[5] = 0.5f * (t1 - t2);
+    }
+    X[4] = r[4] * SVS_PF_T3;
+    X[0] = r[0] * (SVS_PF_SQRT2 * 0.5f);
+}
+
+// scipy.fftpack.idct(X, type=2, norm='ortho') (= DCT-III) for 8 float32 values
+SVS_HD void dct3_8(const float (&X)[8], float (&x)[8]) {
+    float c[8];
+    c[0] = X[0] * SVS_PF_SQRT2;
+    {
+        const float t1 = X[1] + X[7], t2 = X[1] - X[7];
+        c[1] = SVS_PF_T0 * t2 + SVS_PF_T6 * t1;
+        c[7] = SVS_PF_T0 * t1 - SVS_PF_T6 * t2;
+    }
+    {
+        const float t1 = X[2] + X[6], t2 = X[2] - X[6];
+        c[2] = SVS_PF_T1 * t2 + SVS_PF_T5 * t1;
+        c[6] = SVS_PF_T1 * t1 - SVS_PF_T5 * t2;
+    }
+    {
+        const float t1 = X[3] + X[5], t2 = X[3] - X[5];
+        c[3] = SVS_PF_T2 * t2 + SVS_PF_T4 * t1;
+        c[5] = SVS_PF_T2 * t1 - SVS_PF_T4 * t2;
+    }
+    c[4] = X[4] * (2.0f * SVS_PF_T3);
+    float r[8];
+    rfft8_forward(c, r);
+    x[0] = r[0];
+    x[7] = r[7];
+#pragma unroll
+    for (int k = 1; k < 7; k += 2) {  // MPINPLACE(c[k], c[k+1])
+        x[k] = r[k] - r[k + 1];
+        x[k + 1] = r[k + 1] + r[k];
+    }
+}
+}  // namespace pf
+
+// all 64 coefficients of a block, pocketfft arithmetic: vertical transform first (axis 0), then
+// horizontal (config_and_setup.py:135).  Coefficients the caller never reads are dead code.
+SVS_HD void forward_exact(const uint32_t (&rx)[8], const uint32_t (&ry)[8], float (&D)[8][8]) {
+    float V[8][8];
+#define SVS_COL(X, W, B)                                                                \
+    {                                                                                   \
+        const float col[8] = {ubyte_to_float<B>(W[0]), ubyte_to_float<B>(W[1]),         \
+                              ubyte_to_float<B>(W[2]), ubyte_to_float<B>(W[3]),         \
+                              ubyte_to_float<B>(W[4]), ubyte_to_float<B>(W[5]),         \
+                              ubyte_to_float<B>(W[6]), ubyte_to_float<B>(W[7])};        \
+        float out[8];                                                                   \
+        pf::dct2_8(col, out);                                                           \
+        _Pragma("unroll") for (int u = 0; u < 8; ++u) V[u][X] = out[u];                 \
+    }
+    SVS_COL(0, rx, 0) SVS_COL(1, rx, 1) SVS_COL(2, rx, 2) SVS_COL(3, rx, 3)
+    SVS_COL(4, ry, 0) SVS_COL(5, ry, 1) SVS_COL(6, ry, 2) SVS_COL(7, ry, 3)
+#undef SVS_COL
+#pragma unroll
+    for (int u = 0; u < 8; ++u) pf::dct2_8(V[u], D[u]);
+}
+
+// EXACT embed of one block: full DCT -> QIM on 1..n (first nb take payload) -> full IDCT (vertical
+// first, :168) -> clip + truncate (:171).  A block that is entered is always round-tripped, even when
+// nothing is changed (delta <= 0, n = 0): that is what produces the reference's x -> x-1 artefacts.
+template <int U, int QM>
+SVS_HD void embed_block_exact(uint32_t (&rx)[8], uint32_t (&ry)[8], uint32_t n, uint32_t nb, uint32_t hi, uint32_t lo,
+                              const QimParams &qp) {
+    float D[8][8];
+    forward_exact(rx, ry, D);
+#pragma unroll
+    for (int k = 1; k < 8 * U; ++k) {
+        if ((uint32_t)k <= n) {  // wave-uniform
+            const int i = k - 1;
+            const int bit = (int)window_bit(hi, lo, i);
+            const float c = D[k >> 3][k & 7];
+            int q = quant_index<QM>(c, qp);
+            q += bit - (q & 1);
+            float cn;
+            if constexpr (QM == QM_DOUBLE) cn = (float)((double)q * qp.delta_d);
+            else cn = (float)q * qp.delta_f;
+            D[k >> 3][k & 7] = ((uint32_t)i < nb) ? cn : c;
+        }
+    }
+    float P[8][8];  // P[y][v]: vertical inverse of every coefficient column
+#pragma unroll
+    for (int v = 0; v < 8; ++v) {
+        const float col[8] = {D[0][v], D[1][v], D[2][v], D[3][v], D[4][v], D[5][v], D[6][v], D[7][v]};
+        float out[8];
+        pf::dct3_8(col, out);
+#pragma unroll
+        for (int y = 0; y < 8; ++y) P[y][v] = out[y];
+    }
+#pragma unroll
+    for (int y = 0; y < 8; ++y) {
+        float px[8];
+        pf::dct3_8(P[y], px);
+        // np.uint8(np.clip(v, 0, 255)): floor == trunc on the clipped range, the store saturates
+        rx[y] = put_pixel<0>(floorf(px[0]), rx[y]);
+        rx[y] = put_pixel<1>(floorf(px[1]), rx[y]);
+        rx[y] = put_pixel<2>(floorf(px[2]), rx[y]);
+        rx[y] = put_pixel<3>(floorf(px[3]), rx[y]);
+        ry[y] = put_pixel<0>(floorf(px[4]), ry[y]);
+        ry[y] = put_pixel<1>(floorf(px[5]), ry[y]);
+        ry[y] = put_pixel<2>(floorf(px[6]), ry[y]);
+        ry[y] = put_pixel<3>(floorf(px[7]), ry[y]);
+    }
+}
+
+// EXACT extract: parity bits of round(c_k/delta) with pocketfft-identical coefficients
+template <int U, int QM>
+SVS_HD void extract_block_exact(const uint32_t (&rx)[8], const uint32_t (&ry)[8], uint32_t n, const QimParams &qp,
+                                uint32_t &hi, uint32_t &lo) {
+    float D[8][8];
+    forward_exact(rx, ry, D);
+    hi = 0;
+    lo = 0;
+#pragma unroll
+    for (int k = 1; k < 8 * U; ++k) {
+        if ((uint32_t)k <= n) {  // wave-uniform
+            const uint32_t bit = (uint32_t)quant_index<QM>(D[k >> 3][k & 7], qp) & 1u;
+            const int i = k - 1;
+            if (i < 32) hi |= bit << ((31 - i) & 31);
+            else lo |= bit << ((63 - i) & 31);
+        }
+    }
+}
+
 inline int rows_for(int n) { return (n >> 3) + 1; }  // coefficient rows holding flat indices 1..n
 
 }  // namespace svs

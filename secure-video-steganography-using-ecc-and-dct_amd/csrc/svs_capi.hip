@@ -183,6 +183,40 @@ int launch_extract(int rows, uint64_t total, hipStream_t st, const uint8_t *gray
     return SVS_OK;
 }
 
+int launch_embed_exact(int qm, uint64_t total, hipStream_t st, const uint8_t *gray, uint8_t *stego,
+                       const svs::Geometry &g, const svs::QimParams &qp, const uint32_t *bits, uint64_t bit_offset,
+                       uint64_t n_bits, uint32_t n_words) {
+    const dim3 grid((uint32_t)((total + SVS_WG - 1) / SVS_WG));
+    if (qm == svs::QM_DOUBLE)
+        hipLaunchKernelGGL((svs::embed_exact_kernel<svs::QM_DOUBLE>), grid, dim3(SVS_WG), 0, st, gray, stego, g, qp, bits,
+                           bit_offset, n_bits, n_words);
+    else if (qm == svs::QM_POW2)
+        hipLaunchKernelGGL((svs::embed_exact_kernel<svs::QM_POW2>), grid, dim3(SVS_WG), 0, st, gray, stego, g, qp, bits,
+                           bit_offset, n_bits, n_words);
+    else
+        hipLaunchKernelGGL((svs::embed_exact_kernel<svs::QM_F32>), grid, dim3(SVS_WG), 0, st, gray, stego, g, qp, bits,
+                           bit_offset, n_bits, n_words);
+    SVS_HIP(hipGetLastError());
+    return SVS_OK;
+}
+
+template <int QM>
+int launch_extract_exact(int rows, uint64_t total, hipStream_t st, const uint8_t *gray, const svs::Geometry &g,
+                         const svs::QimParams &qp, uint8_t *out, uint64_t out_bytes) {
+    const dim3 grid((uint32_t)((total + SVS_WG - 1) / SVS_WG));
+#define SVS_CASE(R)                                                                                                  \
+    case R:                                                                                                          \
+        hipLaunchKernelGGL((svs::extract_exact_kernel<R, QM>), grid, dim3(SVS_WG), 0, st, gray, g, qp, out, out_bytes); \
+        break;
+    switch (rows) {
+        SVS_CASE(1) SVS_CASE(2) SVS_CASE(3) SVS_CASE(4) SVS_CASE(5) SVS_CASE(6) SVS_CASE(7) SVS_CASE(8)
+        default: return fail(SVS_ERR_INVALID_ARG, "internal: rows=%d", rows);
+    }
+#undef SVS_CASE
+    SVS_HIP(hipGetLastError());
+    return SVS_OK;
+}
+
 struct DevBuf {  // RAII for the host-pointer entry points
     void *p = nullptr;
     ~DevBuf() {
@@ -270,8 +304,8 @@ uint64_t svs_capacity_bits(const svs_planes *p, int n_ac) {
 uint64_t svs_packed_bytes(uint64_t n_bits) { return (n_bits + 7) / 8; }
 
 int svs_embed_dev(const uint8_t *d_gray, uint8_t *d_stego, const svs_planes *planes, double delta, int n_ac,
-                  const uint8_t *d_bits_packed, uint64_t bit_offset, uint64_t n_bits, uint64_t *n_embedded,
-                  void *stream) {
+                  const uint8_t *d_bits_packed, uint64_t bit_offset, uint64_t n_bits, uint32_t flags,
+                  uint64_t *n_embedded, void *stream) {
     svs::Geometry g;
     uint64_t total = 0;
     if (int rc = make_geometry(planes, n_ac, &g, &total)) return rc;
@@ -295,6 +329,28 @@ int svs_embed_dev(const uint8_t *d_gray, uint8_t *d_stego, const svs_planes *pla
     g.xcd_chunk = tune.chunk;
     svs::QimParams qp;
     const int qm = make_qim(use == 0 ? 1.0 : delta, &qp);
+    if (flags & ~SVS_EXACT_POCKETFFT) return fail(SVS_ERR_INVALID_ARG, "unknown flags 0x%x", flags);
+    if (flags & SVS_EXACT_POCKETFFT) {
+        g.xcd_chunk = env_chunk("SVS_EMBED_XCD_CHUNK", kEighth);
+        if (use == 0) {
+            if (n_bits == 0) {   // empty payload: the reference's loops break before the first block
+                if (d_gray == d_stego) return SVS_OK;
+                g.n_ac = 1;
+                return launch_embed<svs::QM_F32, 1>(1, total, st, d_gray, d_stego, g, qp, nullptr, 0, 0, 0);
+            }
+            // delta <= 0 or no coefficients: nothing is consumed, so every block is entered and round-tripped
+            g.n_ac = 0;
+            return launch_embed_exact(svs::QM_F32, total, st, d_gray, d_stego, g, qp, nullptr, 0, 1, 0);
+        }
+        const uint64_t words_x = ((bit_offset + use + 7) / 8 + 3) / 4;
+        if (words_x >= (1ull << 32)) return fail(SVS_ERR_INVALID_ARG, "payload too large for one call");
+        if (int rc = launch_embed_exact(qm, total, st, d_gray, d_stego, g, qp,
+                                        reinterpret_cast<const uint32_t *>(d_bits_packed), bit_offset, use,
+                                        (uint32_t)words_x))
+            return rc;
+        if (n_embedded) *n_embedded = use;
+        return SVS_OK;
+    }
     if (use == 0) {
         // pure copy: every block is "past the budget"
         if (d_gray == d_stego) return SVS_OK;
@@ -321,7 +377,8 @@ int svs_embed_dev(const uint8_t *d_gray, uint8_t *d_stego, const svs_planes *pla
 }
 
 int svs_extract_dev(const uint8_t *d_gray, const svs_planes *planes, double delta, int n_ac,
-                    uint8_t *d_bits_packed_out, uint64_t out_capacity_bytes, uint64_t *n_bits_out, void *stream) {
+                    uint8_t *d_bits_packed_out, uint64_t out_capacity_bytes, uint32_t flags, uint64_t *n_bits_out,
+                    void *stream) {
     svs::Geometry g;
     uint64_t total = 0;
     if (int rc = make_geometry(planes, n_ac, &g, &total)) return rc;
@@ -346,7 +403,12 @@ int svs_extract_dev(const uint8_t *d_gray, const svs_planes *planes, double delt
         const int qm = make_qim(delta, &qp);     // the double mode only differs in requantisation: not needed here
         const int rows = rows_for(n);
         int rc;
-        if (qm == svs::QM_POW2)
+        if (flags & ~SVS_EXACT_POCKETFFT) return fail(SVS_ERR_INVALID_ARG, "unknown flags 0x%x", flags);
+        if (flags & SVS_EXACT_POCKETFFT) {
+            g.xcd_chunk = env_chunk("SVS_EXTRACT_XCD_CHUNK", kEighth);
+            rc = qm == svs::QM_POW2 ? launch_extract_exact<svs::QM_POW2>(rows, total, st, d_gray, g, qp, d_bits_packed_out, bytes)
+                                    : launch_extract_exact<svs::QM_F32>(rows, total, st, d_gray, g, qp, d_bits_packed_out, bytes);
+        } else if (qm == svs::QM_POW2)
             rc = tune.two_blocks ? launch_extract<svs::QM_POW2, 2>(rows, total, st, d_gray, g, qp, d_bits_packed_out, bytes)
                                  : launch_extract<svs::QM_POW2, 1>(rows, total, st, d_gray, g, qp, d_bits_packed_out, bytes);
         else
@@ -359,7 +421,7 @@ int svs_extract_dev(const uint8_t *d_gray, const svs_planes *planes, double delt
 }
 
 int svs_embed(const uint8_t *gray, uint8_t *stego, const svs_planes *planes, double delta, int n_ac,
-              const uint8_t *bits_packed, uint64_t bit_offset, uint64_t n_bits, uint64_t *n_embedded) {
+              const uint8_t *bits_packed, uint64_t bit_offset, uint64_t n_bits, uint32_t flags, uint64_t *n_embedded) {
     svs::Geometry g;
     uint64_t total = 0;
     if (int rc = make_geometry(planes, n_ac, &g, &total)) return rc;
@@ -379,8 +441,11 @@ int svs_embed(const uint8_t *gray, uint8_t *stego, const svs_planes *planes, dou
     SVS_HIP(hipMemset(d_bits.p, 0, bit_alloc));
     if (bit_bytes) SVS_HIP(hipMemcpy(d_bits.p, bits_packed, bit_bytes, hipMemcpyHostToDevice));
     uint64_t done = 0;
+    // a non-empty payload that cannot be embedded (delta <= 0, n_ac = 0) must still reach the kernel as
+    // "non-empty": in EXACT mode every block is then round-tripped, as in the reference
+    const uint64_t pass_bits = use ? use : (n_bits ? 1 : 0);
     if (int rc = svs_embed_dev((const uint8_t *)d_frames.p, (uint8_t *)d_frames.p, planes, delta, n_ac,
-                               (const uint8_t *)d_bits.p, bit_offset, use, &done, nullptr))
+                               (const uint8_t *)d_bits.p, bit_offset, pass_bits, flags, &done, nullptr))
         return rc;
     // copy back pixel bytes only (padding in the caller's stego buffer is left alone)
     if (planes->row_pitch == planes->width && planes->frame_pitch == (int64_t)planes->height * planes->row_pitch) {
@@ -398,7 +463,7 @@ int svs_embed(const uint8_t *gray, uint8_t *stego, const svs_planes *planes, dou
 }
 
 int svs_extract(const uint8_t *gray, const svs_planes *planes, double delta, int n_ac, uint8_t *bits_packed_out,
-                uint64_t out_capacity_bytes, uint64_t *n_bits_out) {
+                uint64_t out_capacity_bytes, uint32_t flags, uint64_t *n_bits_out) {
     svs::Geometry g;
     uint64_t total = 0;
     if (int rc = make_geometry(planes, n_ac, &g, &total)) return rc;
@@ -416,8 +481,8 @@ int svs_extract(const uint8_t *gray, const svs_planes *planes, double delta, int
     SVS_HIP(hipMalloc(&d_bits.p, bytes + 8));
     SVS_HIP(hipMemcpy(d_frames.p, gray, span, hipMemcpyHostToDevice));
     uint64_t got = 0;
-    if (int rc = svs_extract_dev((const uint8_t *)d_frames.p, planes, delta, n_ac, (uint8_t *)d_bits.p, bytes + 8, &got,
-                                 nullptr))
+    if (int rc = svs_extract_dev((const uint8_t *)d_frames.p, planes, delta, n_ac, (uint8_t *)d_bits.p, bytes + 8, flags,
+                                 &got, nullptr))
         return rc;
     SVS_HIP(hipMemcpy(bits_packed_out, d_bits.p, bytes, hipMemcpyDeviceToHost));
     SVS_HIP(hipDeviceSynchronize());

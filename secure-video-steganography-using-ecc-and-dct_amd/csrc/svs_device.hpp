@@ -153,6 +153,45 @@ __global__ __launch_bounds__(SVS_WG) void embed_kernel(const uint8_t *__restrict
     store_rows<BPL>(stego + off, g.row_pitch, v);
 }
 
+// Tail of the extract kernels: a wavefront's 64*BPL consecutive blocks produce exactly n*BPL aligned
+// 64-bit words of the packed stream.  Each lane drops its flag bytes into the wave-private LDS array
+// `mine`; lanes w < 2*BPL*n then compress 32 flags into one dword and store it.
+template <int U, int BPL>
+__device__ __forceinline__ void emit_wave_bits(uint8_t *mine, uint32_t lane, uint64_t wave_first_block, uint32_t n,
+                                               uint32_t hi_a, uint32_t lo_a, uint32_t hi_b, uint32_t lo_b,
+                                               uint8_t *__restrict__ out, uint64_t out_bytes) {
+    // lane writes its n*BPL flag bytes at [lane*BPL*n, ...)
+#pragma unroll
+    for (int i = 0; i < 8 * U - 1; ++i) {
+        if ((uint32_t)i < n) {
+            mine[lane * BPL * n + i] = (uint8_t)window_bit(hi_a, lo_a, i);
+            if constexpr (BPL == 2) mine[(lane * BPL + 1) * n + i] = (uint8_t)window_bit(hi_b, lo_b, i);
+        }
+    }
+    __syncthreads();
+
+    // 64*BPL*n flag bytes -> 2*BPL*n dwords of packed stream; dword w covers flags [32w, 32w+32)
+    const uint64_t wave_byte0 = wave_first_block * n / 8u;  // multiple of 8 bytes
+    for (uint32_t w = lane; w < 2u * BPL * n; w += 64u) {
+        const uint4 f0 = *reinterpret_cast<const uint4 *>(mine + 32u * w);
+        const uint4 f1 = *reinterpret_cast<const uint4 *>(mine + 32u * w + 16u);
+        // four 0/1 bytes (first flag in the low byte) -> nibble with the first flag as MSB
+#define SVS_NIB(X) ((((X) * 0x08040201u) >> 24) & 0xFu)
+        const uint32_t b0 = (SVS_NIB(f0.x) << 4) | SVS_NIB(f0.y);
+        const uint32_t b1 = (SVS_NIB(f0.z) << 4) | SVS_NIB(f0.w);
+        const uint32_t b2 = (SVS_NIB(f1.x) << 4) | SVS_NIB(f1.y);
+        const uint32_t b3 = (SVS_NIB(f1.z) << 4) | SVS_NIB(f1.w);
+#undef SVS_NIB
+        const uint32_t word = b0 | (b1 << 8) | (b2 << 16) | (b3 << 24);
+        const uint64_t at = wave_byte0 + 4ull * w;
+        if (at + 4 <= out_bytes) {
+            *reinterpret_cast<uint32_t *>(out + at) = word;
+        } else {
+            for (uint32_t j = 0; j < 4 && at + j < out_bytes; ++j) out[at + j] = (uint8_t)(word >> (8 * j));
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------
 // EXTRACT: one lane = BPL adjacent blocks; a wavefront's 64*BPL blocks produce exactly n*BPL
 // aligned 64-bit words of the packed stream (stream bit = global block * n + i), assembled through
@@ -186,38 +225,64 @@ __global__ __launch_bounds__(SVS_WG) void extract_kernel(const uint8_t *__restri
         }
     }
 
-    // lane writes its n*BPL flag bytes at [lane*BPL*n, ...)
-    uint8_t *mine = &flags[wave][0];
-#pragma unroll
-    for (int i = 0; i < 8 * U - 1; ++i) {
-        if ((uint32_t)i < n) {
-            mine[lane * BPL * n + i] = (uint8_t)window_bit(hi_a, lo_a, i);
-            if constexpr (BPL == 2) mine[(lane * BPL + 1) * n + i] = (uint8_t)window_bit(hi_b, lo_b, i);
-        }
-    }
-    __syncthreads();
+    emit_wave_bits<U, BPL>(&flags[wave][0], lane, ((uint64_t)tile * (uint32_t)SVS_WG + wave * 64u) * BPL, n, hi_a, lo_a,
+                           hi_b, lo_b, out, out_bytes);
+}
 
-    // 64*BPL*n flag bytes -> 2*BPL*n dwords of packed stream; dword w covers flags [32w, 32w+32)
-    const uint64_t wave_first_block = ((uint64_t)tile * (uint32_t)SVS_WG + wave * 64u) * BPL;
-    const uint64_t wave_byte0 = wave_first_block * n / 8u;  // multiple of 8 bytes
-    for (uint32_t w = lane; w < 2u * BPL * n; w += 64u) {
-        const uint4 f0 = *reinterpret_cast<const uint4 *>(mine + 32u * w);
-        const uint4 f1 = *reinterpret_cast<const uint4 *>(mine + 32u * w + 16u);
-        // four 0/1 bytes (first flag in the low byte) -> nibble with the first flag as MSB
-#define SVS_NIB(X) ((((X) * 0x08040201u) >> 24) & 0xFu)
-        const uint32_t b0 = (SVS_NIB(f0.x) << 4) | SVS_NIB(f0.y);
-        const uint32_t b1 = (SVS_NIB(f0.z) << 4) | SVS_NIB(f0.w);
-        const uint32_t b2 = (SVS_NIB(f1.x) << 4) | SVS_NIB(f1.y);
-        const uint32_t b3 = (SVS_NIB(f1.z) << 4) | SVS_NIB(f1.w);
-#undef SVS_NIB
-        const uint32_t word = b0 | (b1 << 8) | (b2 << 16) | (b3 << 24);
-        const uint64_t at = wave_byte0 + 4ull * w;
-        if (at + 4 <= out_bytes) {
-            *reinterpret_cast<uint32_t *>(out + at) = word;
-        } else {
-            for (uint32_t j = 0; j < 4 && at + j < out_bytes; ++j) out[at + j] = (uint8_t)(word >> (8 * j));
-        }
+// ---------------------------------------------------------------------------------------
+// EXACT-mode kernels (pocketfft-identical arithmetic, svs_block.hpp "EXACT mode"): one block per lane.
+// The embed kernel transforms all 64 coefficients both ways (about 2 700 VALU instructions per block),
+// so it is VALU-bound at roughly 40 % of the fast kernel's rate; it exists for bit-identical output.
+// ---------------------------------------------------------------------------------------
+template <int QM>
+__global__ __launch_bounds__(SVS_WG) void embed_exact_kernel(const uint8_t *__restrict__ gray,
+                                                          uint8_t *__restrict__ stego, const Geometry g,
+                                                          const QimParams qp,
+                                                          const uint32_t *__restrict__ bits,
+                                                          const uint64_t bit_offset, const uint64_t n_bits,
+                                                          const uint32_t n_words) {
+    const uint32_t gblock = tile_id(g.xcd_chunk) * (uint32_t)SVS_WG + threadIdx.x;
+    if (gblock >= g.total_blocks) return;
+    const int64_t off = block_offset(gblock, g);
+    typename RowVec<1>::type v[8];
+    load_rows<1>(gray + off, g.row_pitch, v);
+    const uint32_t n = g.n_ac;  // 0 = round-trip every block without touching a coefficient
+    const uint64_t first = (uint64_t)gblock * n;
+    if (first >= n_bits) {
+        if (stego != gray) store_rows<1>(stego + off, g.row_pitch, v);
+        return;
     }
+    uint32_t ax[8], ay[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) { ax[r] = v[r].x; ay[r] = v[r].y; }
+    uint32_t hi, lo;
+    payload_window(bits, n_words, bit_offset + first, hi, lo);
+    embed_block_exact<8, QM>(ax, ay, n, block_budget(first, n_bits, n), hi, lo, qp);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) { v[r].x = ax[r]; v[r].y = ay[r]; }
+    store_rows<1>(stego + off, g.row_pitch, v);
+}
+
+template <int U, int QM>
+__global__ __launch_bounds__(SVS_WG) void extract_exact_kernel(const uint8_t *__restrict__ gray, const Geometry g,
+                                                            const QimParams qp, uint8_t *__restrict__ out,
+                                                            const uint64_t out_bytes) {
+    __shared__ __attribute__((aligned(16))) uint8_t flags[SVS_WG / 64][64 * 64];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t tile = tile_id(g.xcd_chunk);
+    const uint32_t gblock = tile * (uint32_t)SVS_WG + threadIdx.x;
+    const uint32_t n = g.n_ac;
+    uint32_t hi = 0, lo = 0;
+    if (gblock < g.total_blocks) {
+        typename RowVec<1>::type v[8];
+        load_rows<1>(gray + block_offset(gblock, g), g.row_pitch, v);
+        uint32_t ax[8], ay[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) { ax[r] = v[r].x; ay[r] = v[r].y; }
+        extract_block_exact<U, QM>(ax, ay, n, qp, hi, lo);
+    }
+    emit_wave_bits<U, 1>(&flags[wave][0], lane, (uint64_t)tile * (uint32_t)SVS_WG + wave * 64u, n, hi, lo, 0u, 0u, out,
+                         out_bytes);
 }
 
 // ---------------------------------------------------------------------------------------

@@ -13,6 +13,7 @@ the reference operator's '0'/'1' string.
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -20,6 +21,23 @@ from . import native
 from .native import Planes
 
 MAX_AC = 63
+
+# Transform mode (include/svsdct.h `flags`):
+#   "fast"   FMA-factored DCT on the coefficient rows the payload touches - contract parity (bits exact,
+#            PSNR within 0.01 dB), HBM-roofline speed.  Default of the device-pointer (throughput) level.
+#   "exact"  pocketfft-identical arithmetic - stego pixels bit-identical to the reference.  Default of the
+#            NumPy level, which the drop-in operator and the video pipelines use (they are I/O bound).
+# SVS_DCT_MODE=fast|exact overrides both defaults.
+_ENV_MODE = os.environ.get("SVS_DCT_MODE")
+
+
+def mode_flags(mode, default: str) -> int:
+    mode = mode or _ENV_MODE or default
+    if mode == "fast":
+        return 0
+    if mode == "exact":
+        return native.SVS_EXACT_POCKETFFT
+    raise ValueError(f"unknown transform mode {mode!r} (use 'fast' or 'exact')")
 
 
 def clamp_ac(n_ac) -> int:
@@ -71,7 +89,7 @@ def _as_stack(frames: np.ndarray) -> np.ndarray:
 
 
 def embed_frames(frames: np.ndarray, delta, n_ac, bits, bit_offset: int = 0, n_bits: int | None = None,
-                 device: int = 0):
+                 device: int = 0, mode: str | None = None):
     """Embed a bit stream into a stack of gray frames on the GPU.
 
     frames : uint8 [F,H,W] (or [H,W]);  bits : 0/1 array or '0'/'1' str (the stream; bit
@@ -93,12 +111,12 @@ def embed_frames(frames: np.ndarray, delta, n_ac, bits, bit_offset: int = 0, n_b
     done = C.c_uint64(0)
     planes = Planes.contiguous(f, h, w)
     rc = lib.svs_embed(stack.ctypes.data, stego.ctypes.data, C.byref(planes), float(delta), int(n_ac),
-                       packed.ctypes.data, int(bit_offset), int(n_bits), C.byref(done))
+                       packed.ctypes.data, int(bit_offset), int(n_bits), mode_flags(mode, "exact"), C.byref(done))
     native.check(rc, "svs_embed")
     return stego, int(done.value)
 
 
-def extract_frames(frames: np.ndarray, delta, n_ac, device: int = 0):
+def extract_frames(frames: np.ndarray, delta, n_ac, device: int = 0, mode: str | None = None):
     """Extract the packed bit stream of a stack of gray frames on the GPU.
     Returns (packed uint8 [ceil(n_bits/8)], n_bits)."""
     lib = native.load()
@@ -110,7 +128,7 @@ def extract_frames(frames: np.ndarray, delta, n_ac, device: int = 0):
     got = C.c_uint64(0)
     planes = Planes.contiguous(f, h, w)
     rc = lib.svs_extract(stack.ctypes.data, C.byref(planes), float(delta), int(n_ac), out.ctypes.data,
-                         out.size, C.byref(got))
+                         out.size, mode_flags(mode, "exact"), C.byref(got))
     native.check(rc, "svs_extract")
     n = int(got.value)
     return out[: (n + 7) // 8], n
@@ -118,21 +136,23 @@ def extract_frames(frames: np.ndarray, delta, n_ac, device: int = 0):
 
 # ---- device-pointer level -------------------------------------------------------------------
 def embed_device(d_gray: int, d_stego: int, planes: Planes, delta, n_ac, d_bits_packed: int,
-                 bit_offset: int, n_bits: int, stream: int = 0) -> int:
+                 bit_offset: int, n_bits: int, stream: int = 0, mode: str | None = None) -> int:
     """Enqueue the embed kernel on `stream` (a hipStream_t handle as int); returns bits embedded."""
     done = C.c_uint64(0)
     rc = native.load().svs_embed_dev(d_gray, d_stego, C.byref(planes), float(delta), int(n_ac), d_bits_packed,
-                                     int(bit_offset), int(n_bits), C.byref(done), stream or None)
+                                     int(bit_offset), int(n_bits), mode_flags(mode, "fast"), C.byref(done),
+                                     stream or None)
     native.check(rc, "svs_embed_dev")
     return int(done.value)
 
 
 def extract_device(d_gray: int, planes: Planes, delta, n_ac, d_bits_out: int, out_capacity_bytes: int,
-                   stream: int = 0) -> int:
+                   stream: int = 0, mode: str | None = None) -> int:
     """Enqueue the extract kernel on `stream`; returns the number of bits the batch yields."""
     got = C.c_uint64(0)
     rc = native.load().svs_extract_dev(d_gray, C.byref(planes), float(delta), int(n_ac), d_bits_out,
-                                       int(out_capacity_bytes), C.byref(got), stream or None)
+                                       int(out_capacity_bytes), mode_flags(mode, "fast"), C.byref(got),
+                                       stream or None)
     native.check(rc, "svs_extract_dev")
     return int(got.value)
 

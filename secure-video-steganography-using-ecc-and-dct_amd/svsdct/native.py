@@ -17,6 +17,8 @@ SVS_ERR_INVALID_ARG = -1
 SVS_ERR_HIP = -2
 SVS_ERR_NO_DEVICE = -3
 SVS_ERR_CAPACITY = -4
+SVS_EXACT_POCKETFFT = 1      # flags bit: pocketfft-identical arithmetic (include/svsdct.h)
+ABI_VERSION = 2
 
 
 class SvsNativeError(RuntimeError):
@@ -54,10 +56,10 @@ SIGNATURES = {
     "svs_stream_synchronize": (C.c_int, [C.c_void_p]),
     "svs_capacity_bits": (C.c_uint64, [_PL, C.c_int]),
     "svs_packed_bytes": (C.c_uint64, [C.c_uint64]),
-    "svs_embed_dev": (C.c_int, [_u8p, _u8p, _PL, C.c_double, C.c_int, _u8p, C.c_uint64, C.c_uint64, _u64p, C.c_void_p]),
-    "svs_embed": (C.c_int, [_u8p, _u8p, _PL, C.c_double, C.c_int, _u8p, C.c_uint64, C.c_uint64, _u64p]),
-    "svs_extract_dev": (C.c_int, [_u8p, _PL, C.c_double, C.c_int, _u8p, C.c_uint64, _u64p, C.c_void_p]),
-    "svs_extract": (C.c_int, [_u8p, _PL, C.c_double, C.c_int, _u8p, C.c_uint64, _u64p]),
+    "svs_embed_dev": (C.c_int, [_u8p, _u8p, _PL, C.c_double, C.c_int, _u8p, C.c_uint64, C.c_uint64, C.c_uint32, _u64p, C.c_void_p]),
+    "svs_embed": (C.c_int, [_u8p, _u8p, _PL, C.c_double, C.c_int, _u8p, C.c_uint64, C.c_uint64, C.c_uint32, _u64p]),
+    "svs_extract_dev": (C.c_int, [_u8p, _PL, C.c_double, C.c_int, _u8p, C.c_uint64, C.c_uint32, _u64p, C.c_void_p]),
+    "svs_extract": (C.c_int, [_u8p, _PL, C.c_double, C.c_int, _u8p, C.c_uint64, C.c_uint32, _u64p]),
     "svs_fill_synthetic_dev": (C.c_int, [_u8p, _PL, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]),
     "svs_fill_bits_dev": (C.c_int, [_u8p, C.c_uint64, C.c_uint32, C.c_uint64, C.c_void_p]),
     "svs_frame_sse_dev": (C.c_int, [_u8p, _u8p, _PL, C.c_void_p, C.c_void_p]),
@@ -87,8 +89,9 @@ def load() -> C.CDLL:
             raise SvsNativeError(f"{LIB_PATH} does not export {name}; rebuild it") from exc
         fn.restype = res
         fn.argtypes = args
-    if lib.svs_abi_version() != 1:
-        raise SvsNativeError(f"ABI version mismatch: library reports {lib.svs_abi_version()}, binding expects 1")
+    if lib.svs_abi_version() != ABI_VERSION:
+        raise SvsNativeError(f"ABI version mismatch: library reports {lib.svs_abi_version()}, binding expects "
+                             f"{ABI_VERSION}; rebuild libsvsdct.so")
     _lib = lib
     return lib
 

@@ -80,15 +80,27 @@ extern "C" {
 
 // frames: contiguous [F][H][W]; bits: packed MSB-first, padded by the caller to a multiple of 4 bytes
 uint64_t emu_embed(const uint8_t *gray, uint8_t *stego, int F, int H, int W, double delta, int n_ac,
-                   const uint8_t *bits, uint64_t bits_bytes, uint64_t bit_offset, uint64_t n_bits) {
+                   const uint8_t *bits, uint64_t bits_bytes, uint64_t bit_offset, uint64_t n_bits, int exact) {
     const int n = n_ac < 0 ? 0 : (n_ac > 63 ? 63 : n_ac);
     const uint64_t bpf = (uint64_t)(H / 8) * (W / 8), total = bpf * F;
     std::memcpy(stego, gray, (size_t)F * H * W);
     uint64_t use = n_bits < total * n ? n_bits : total * n;
     if (!(delta > 0.0) || n == 0) use = 0;
-    if (use == 0) return 0;
     svs::QimParams qp;
-    const int dbl = make_qim(delta, &qp);
+    const int dbl = make_qim(use ? delta : 1.0, &qp);
+    if (use == 0) {
+        if (exact && n_bits > 0) {  // nothing consumed -> every block entered and round-tripped
+            for (uint64_t gb = 0; gb < total; ++gb) {
+                const uint64_t f = gb / bpf, b = gb % bpf;
+                uint8_t *p = stego + f * (uint64_t)H * W + (b / (W / 8)) * 8 * W + (b % (W / 8)) * 8;
+                Blk raw;
+                raw.load(p, (size_t)W);
+                svs::embed_block_exact<8, svs::QM_F32>(raw.x, raw.y, 0, 0, 0, 0, qp);
+                raw.store(p, (size_t)W);
+            }
+        }
+        return 0;
+    }
     const uint32_t n_words = (uint32_t)(bits_bytes / 4);
     for (uint64_t gb = 0; gb < total; ++gb) {
         const uint64_t first = gb * n;
@@ -101,14 +113,17 @@ uint64_t emu_embed(const uint8_t *gray, uint8_t *stego, int F, int H, int W, dou
         raw.load(p, (size_t)W);
         uint32_t hi, lo;
         svs::payload_window(reinterpret_cast<const uint32_t *>(bits), n_words, bit_offset + first, hi, lo);
-        embed_dispatch(svs::rows_for(n), raw, (uint32_t)n, nb, hi, lo, qp, dbl);
+        if (!exact) embed_dispatch(svs::rows_for(n), raw, (uint32_t)n, nb, hi, lo, qp, dbl);
+        else if (dbl == svs::QM_DOUBLE) svs::embed_block_exact<8, svs::QM_DOUBLE>(raw.x, raw.y, (uint32_t)n, nb, hi, lo, qp);
+        else if (dbl == svs::QM_POW2) svs::embed_block_exact<8, svs::QM_POW2>(raw.x, raw.y, (uint32_t)n, nb, hi, lo, qp);
+        else svs::embed_block_exact<8, svs::QM_F32>(raw.x, raw.y, (uint32_t)n, nb, hi, lo, qp);
         raw.store(p, (size_t)W);
     }
     return use;
 }
 
 // out_flags: one byte (0/1) per extracted bit, F*(H/8)*(W/8)*n entries
-uint64_t emu_extract(const uint8_t *gray, int F, int H, int W, double delta, int n_ac, uint8_t *out_flags) {
+uint64_t emu_extract(const uint8_t *gray, int F, int H, int W, double delta, int n_ac, uint8_t *out_flags, int exact) {
     const int n = n_ac < 0 ? 0 : (n_ac > 63 ? 63 : n_ac);
     const uint64_t bpf = (uint64_t)(H / 8) * (W / 8), total = bpf * F;
     if (n == 0) return 0;
@@ -125,7 +140,10 @@ uint64_t emu_extract(const uint8_t *gray, int F, int H, int W, double delta, int
         Blk raw;
         raw.load(p, (size_t)W);
         uint32_t hi, lo;
-        if (qm == svs::QM_POW2) extract_dispatch<svs::QM_POW2>(svs::rows_for(n), raw, (uint32_t)n, qp, hi, lo);
+        if (exact) {
+            if (qm == svs::QM_POW2) svs::extract_block_exact<8, svs::QM_POW2>(raw.x, raw.y, (uint32_t)n, qp, hi, lo);
+            else svs::extract_block_exact<8, svs::QM_F32>(raw.x, raw.y, (uint32_t)n, qp, hi, lo);
+        } else if (qm == svs::QM_POW2) extract_dispatch<svs::QM_POW2>(svs::rows_for(n), raw, (uint32_t)n, qp, hi, lo);
         else extract_dispatch<svs::QM_F32>(svs::rows_for(n), raw, (uint32_t)n, qp, hi, lo);
         for (int i = 0; i < n; ++i) out_flags[gb * n + i] = (uint8_t)svs::window_bit(hi, lo, i);
     }
@@ -149,6 +167,21 @@ uint64_t emu_quant_mismatches(const float *c, uint64_t n, double delta) {
     for (uint64_t i = 0; i < n; ++i)
         bad += svs::quant_index<svs::QM_F32>(c[i], qp) != svs::quant_index_by_division(c[i], qp.delta_f);
     return bad;
+}
+
+// pocketfft-identical 8-point transforms (type 2 / type 3, norm='ortho')
+void emu_pf_dct2(const float *x, float *X) {
+    float a[8], b[8];
+    std::memcpy(a, x, sizeof a);
+    svs::pf::dct2_8(a, b);
+    std::memcpy(X, b, sizeof b);
+}
+
+void emu_pf_dct3(const float *X, float *x) {
+    float a[8], b[8];
+    std::memcpy(a, X, sizeof a);
+    svs::pf::dct3_8(a, b);
+    std::memcpy(x, b, sizeof b);
 }
 
 void emu_idct8(const float *X, float *x) {

@@ -1,0 +1,63 @@
+"""CPU tier: EXACT mode (csrc/svs_block.hpp, namespace pf + *_exact) - the bit-for-bit restatement of
+pocketfft's float32 8-point DCT-II / DCT-III that scipy.fftpack uses.  With it the whole operator must
+equal the reference BIT FOR BIT: stego pixels, extracted bits, rounding ties, round-trip artefacts."""
+import numpy as np
+from scipy.fftpack import dct, idct
+
+from testlib import case_inputs, emu_embed, emu_extract, golden_bits, hostemu, sha, single_frame_cases
+from oracle import qim_dct_oracle as orc
+from svsdct import synth
+
+
+def test_pocketfft_transforms_are_bit_identical_to_scipy():
+    lib = hostemu()
+    rng = np.random.default_rng(11)
+    samples = np.concatenate([
+        rng.integers(0, 256, (20000, 8)).astype(np.float32),                 # pixel columns
+        rng.normal(0, 300, (20000, 8)).astype(np.float32),                   # coefficient-like
+        (rng.integers(-16000, 16000, (20000, 8)) / 8).astype(np.float32),    # exact multiples of 1/8
+        np.eye(8, dtype=np.float32) * 255, np.zeros((1, 8), np.float32), np.full((1, 8), 128, np.float32)])
+    want2 = dct(samples, axis=1, norm="ortho")
+    want3 = idct(samples, axis=1, norm="ortho")
+    assert want2.dtype == np.float32
+    got2, got3 = np.empty_like(samples), np.empty_like(samples)
+    for i, row in enumerate(samples):
+        row = np.ascontiguousarray(row)
+        lib.emu_pf_dct2(row.ctypes.data, got2[i].ctypes.data)
+        lib.emu_pf_dct3(row.ctypes.data, got3[i].ctypes.data)
+    assert np.array_equal(got2.view(np.uint32), want2.view(np.uint32))       # bit patterns, signed zeros included
+    assert np.array_equal(got3.view(np.uint32), want3.view(np.uint32))
+
+
+def test_every_golden_vector_bit_for_bit(golden):
+    arrays, meta = golden
+    for name in single_frame_cases(meta):
+        info, gray, payload = case_inputs(arrays, meta, name)
+        delta, n_ac = info["delta"], info["n_ac"]
+        stego, used = emu_embed(gray, delta, n_ac, payload, exact=True)
+        assert used == info["used"], name
+        assert sha(stego[0]) == info["stego_sha256"], name                   # pixels identical to the reference
+        for src, tag in ((stego[0], "ext_stego"), (gray, "ext_cover")):      # ties included: no mask needed
+            assert np.array_equal(emu_extract(src, delta, n_ac, exact=True),
+                                  golden_bits(arrays, name, tag, info[tag + "_len"])), (name, tag)
+
+
+def test_stream_and_partial_budgets_bit_for_bit(golden):
+    arrays, meta = golden
+    info = meta["cases"]["G8_stream"]
+    frames = synth.synthetic_frames(3, 32, 48, seed=info["synth_seed"])
+    stego, used = emu_embed(frames, info["delta"], info["n_ac"], arrays["G8_stream/payload"], exact=True)
+    assert used == info["used"]
+    for k in range(3):
+        assert np.array_equal(stego[k], arrays[f"G8_stream/stego{k}"])
+
+
+def test_larger_random_frames_against_oracle():
+    rng = np.random.default_rng(2)
+    for (h, w), n_ac, delta in [((96, 160), 10, 8), ((64, 64), 63, 5), ((40, 72), 36, 7.5), ((64, 96), 4, 3)]:
+        gray = rng.integers(0, 256, (h, w), dtype=np.uint8)
+        bits = rng.integers(0, 2, (h // 8) * (w // 8) * n_ac - 5).astype(np.uint8)
+        stego, used = emu_embed(gray, delta, n_ac, bits, exact=True)
+        _, want, want_used = orc.frame_embed(gray, delta, bits, n_ac)
+        assert used == want_used and np.array_equal(stego[0], want)
+        assert np.array_equal(emu_extract(gray, delta, n_ac, exact=True), orc.frame_extract_bits(gray, delta, n_ac))

@@ -13,7 +13,7 @@ import os
 import numpy as np
 import pytest
 
-from testlib import (NOISE_ONLY_CASES, REPO, case_inputs, emu_embed, emu_extract, exact_tie_mask, golden_bits,
+from testlib import (NOISE_ONLY_CASES, REPO, case_inputs, emu_embed, emu_extract, exact_tie_mask, golden_bits, sha,
                      single_frame_cases)
 from oracle import qim_dct_oracle as orc
 from svsdct import batch, native, synth
@@ -38,22 +38,62 @@ def test_device_is_gfx950():
     assert native.device_arch(0).startswith("gfx950")
 
 
+def test_exact_mode_golden_vectors_bit_for_bit(golden):
+    """EXACT mode (pocketfft-identical arithmetic): stego PIXELS, bit counts and extracted bits equal the
+    reference's in every golden case - ties, flat-block and delta <= 0 round-trip artefacts included."""
+    arrays, meta = golden
+    for name in single_frame_cases(meta):
+        info, gray, payload = case_inputs(arrays, meta, name)
+        delta, n_ac = info["delta"], info["n_ac"]
+        stego, used = batch.embed_frames(gray, delta, n_ac, payload, mode="exact")
+        assert used == info["used"], name
+        assert sha(stego[0]) == info["stego_sha256"], name
+        for src, tag in ((stego[0], "ext_stego"), (gray, "ext_cover")):
+            packed, n_bits = batch.extract_frames(src, delta, n_ac, mode="exact")
+            assert n_bits == info[tag + "_len"], name
+            assert np.array_equal(packed, arrays[f"{name}/{tag}"][:packed.size]), (name, tag)
+        _REPORT["exact/" + name] = {"pixels": int(gray.size), "pixels_differing_from_reference": 0}
+    info = meta["cases"]["G8_stream"]
+    frames = synth.synthetic_frames(3, 32, 48, seed=info["synth_seed"])
+    stego, used = batch.embed_frames(frames, info["delta"], info["n_ac"], arrays["G8_stream/payload"], mode="exact")
+    assert used == info["used"]
+    for k in range(3):
+        assert np.array_equal(stego[k], arrays[f"G8_stream/stego{k}"])
+
+
+@pytest.mark.parametrize("shape,n_ac,delta,frames", [((1080, 1920), 10, 8, 2), ((2160, 3840), 3, 8, 1),
+                                                      ((480, 640), 10, 20, 2), ((360, 640), 63, 4, 1)])
+def test_exact_mode_full_size_equals_oracle(shape, n_ac, delta, frames):
+    h, w = shape
+    cover = synth.synthetic_frames(frames, h, w, seed=h ^ n_ac, lo=0, span=256)     # clipping included
+    cap = batch.capacity_bits(frames, h, w, n_ac)
+    payload = synth.synthetic_bits(cap - 17, seed=h)
+    stego, used = batch.embed_frames(cover, delta, n_ac, payload, mode="exact")
+    want, want_used = orc.batch_embed(cover, delta, payload, n_ac)
+    assert used == want_used
+    assert np.array_equal(stego, want)                                               # every pixel
+    packed, n_bits = batch.extract_frames(stego, delta, n_ac, mode="exact")
+    assert np.array_equal(np.unpackbits(packed, count=n_bits), orc.batch_extract_bits(want, delta, n_ac))
+    packed, n_bits = batch.extract_frames(cover, delta, n_ac, mode="exact")          # ties resolved as scipy does
+    assert np.array_equal(np.unpackbits(packed, count=n_bits), orc.batch_extract_bits(cover, delta, n_ac))
+
+
 def test_golden_vectors(golden):
     arrays, meta = golden
     for name in single_frame_cases(meta):
         info, gray, payload = case_inputs(arrays, meta, name)
         delta, n_ac = info["delta"], info["n_ac"]
-        stego, used = batch.embed_frames(gray, delta, n_ac, payload)
+        stego, used = batch.embed_frames(gray, delta, n_ac, payload, mode="fast")
         stego = stego[0]
         _, ref_stego, ref_used = orc.frame_embed(gray, delta, payload, n_ac)
 
         # (a) extraction from the REFERENCE's stego frame is bit-exact
-        packed, n_bits = batch.extract_frames(ref_stego, delta, n_ac)
+        packed, n_bits = batch.extract_frames(ref_stego, delta, n_ac, mode="fast")
         assert n_bits == info["ext_stego_len"], name
         assert np.array_equal(np.unpackbits(packed, count=n_bits),
                               golden_bits(arrays, name, "ext_stego", n_bits)), name
         # (b) extraction from our own stego frame agrees with the oracle on the same frame
-        packed, n_bits = batch.extract_frames(stego, delta, n_ac)
+        packed, n_bits = batch.extract_frames(stego, delta, n_ac, mode="fast")
         own = np.unpackbits(packed, count=n_bits)
         assert np.array_equal(own, orc.frame_extract_bits(stego, delta, n_ac)), name
         # the kernels compute exactly what the CPU build of the same header computes
@@ -75,7 +115,7 @@ def test_golden_vectors(golden):
         else:
             assert np.array_equal(stego, gray), name
         # (e) extraction from the cover: identical except where c/delta is an exact rounding tie
-        packed, n_bits = batch.extract_frames(gray, delta, n_ac)
+        packed, n_bits = batch.extract_frames(gray, delta, n_ac, mode="fast")
         cov = np.unpackbits(packed, count=n_bits)
         want = golden_bits(arrays, name, "ext_cover", info["ext_cover_len"])
         ties = exact_tie_mask(gray, delta, n_ac).reshape(-1)
@@ -88,11 +128,11 @@ def test_reference_ber_at_delta4_is_reproduced(golden):
     identical bits to the oracle on the same frames, hence the same error positions."""
     arrays, meta = golden
     info, gray, payload = case_inputs(arrays, meta, "G7_d4_n3")
-    stego, used = batch.embed_frames(gray, 4, 3, payload)
-    packed, n_bits = batch.extract_frames(arrays["G7_d4_n3/stego"], 4, 3)
+    stego, used = batch.embed_frames(gray, 4, 3, payload, mode="fast")
+    packed, n_bits = batch.extract_frames(arrays["G7_d4_n3/stego"], 4, 3, mode="fast")
     got = np.unpackbits(packed, count=n_bits)
     assert np.array_equal(np.nonzero(got != payload)[0], arrays["G7_d4_n3/error_positions"])
-    packed, n_bits = batch.extract_frames(stego[0], 4, 3)
+    packed, n_bits = batch.extract_frames(stego[0], 4, 3, mode="fast")
     assert np.array_equal(np.unpackbits(packed, count=n_bits), orc.frame_extract_bits(stego[0], 4, 3))
 
 
@@ -101,12 +141,12 @@ def test_stream_over_frames(golden):
     info = meta["cases"]["G8_stream"]
     frames = synth.synthetic_frames(3, 32, 48, seed=info["synth_seed"])
     payload = arrays["G8_stream/payload"]
-    stego, used = batch.embed_frames(frames, info["delta"], info["n_ac"], payload)
+    stego, used = batch.embed_frames(frames, info["delta"], info["n_ac"], payload, mode="fast")
     assert used == info["used"]
     for k in range(3):
         assert np.array_equal(stego[k], arrays[f"G8_stream/stego{k}"]), k
     assert np.array_equal(stego[2], frames[2])
-    packed, n_bits = batch.extract_frames(stego, info["delta"], info["n_ac"])
+    packed, n_bits = batch.extract_frames(stego, info["delta"], info["n_ac"], mode="fast")
     bits = np.unpackbits(packed, count=n_bits)
     assert np.array_equal(bits[:used], payload)
     for k in range(3):
@@ -115,7 +155,7 @@ def test_stream_over_frames(golden):
     # bit_offset into a longer shared buffer (how ranks index one payload)
     junk = synth.synthetic_bits(61, seed=3)
     stego2, used2 = batch.embed_frames(frames, info["delta"], info["n_ac"], np.concatenate([junk, payload]),
-                                       bit_offset=61)
+                                       bit_offset=61, mode="fast")
     assert used2 == used and np.array_equal(stego2, stego)
 
 
@@ -131,9 +171,9 @@ def test_full_size_round_trip_and_oracle_agreement(shape, n_ac, delta, frames):
     cover = synth.synthetic_frames(frames, h, w, seed=h + n_ac)
     cap = batch.capacity_bits(frames, h, w, n_ac)
     payload = synth.synthetic_bits(cap, seed=h + n_ac)
-    stego, used = batch.embed_frames(cover, delta, n_ac, payload)
+    stego, used = batch.embed_frames(cover, delta, n_ac, payload, mode="fast")
     assert used == cap
-    packed, n_bits = batch.extract_frames(stego, delta, n_ac)
+    packed, n_bits = batch.extract_frames(stego, delta, n_ac, mode="fast")
     got = np.unpackbits(packed, count=n_bits)
     assert n_bits == cap
     if n_ac <= 7 or delta >= 8 and n_ac < 63:
@@ -156,14 +196,14 @@ def test_full_size_round_trip_and_oracle_agreement(shape, n_ac, delta, frames):
 def test_idempotent_and_deterministic():
     cover = synth.synthetic_frames(2, 64, 64, seed=1)
     payload = synth.synthetic_bits(2 * 64 * 5, seed=1)
-    a, _ = batch.embed_frames(cover, 8, 5, payload)
-    b, _ = batch.embed_frames(cover, 8, 5, payload)
+    a, _ = batch.embed_frames(cover, 8, 5, payload, mode="fast")
+    b, _ = batch.embed_frames(cover, 8, 5, payload, mode="fast")
     assert np.array_equal(a, b)
     # embedding the bits a frame already carries changes the quantisation index by nothing: the
     # stego frame's own bits re-embedded give a frame that still decodes to them
-    packed, n = batch.extract_frames(a, 8, 5)
-    c, _ = batch.embed_frames(a, 8, 5, np.unpackbits(packed, count=n))
-    packed2, _ = batch.extract_frames(c, 8, 5)
+    packed, n = batch.extract_frames(a, 8, 5, mode="fast")
+    c, _ = batch.embed_frames(a, 8, 5, np.unpackbits(packed, count=n), mode="fast")
+    packed2, _ = batch.extract_frames(c, 8, 5, mode="fast")
     assert np.array_equal(packed, packed2)
 
 
@@ -216,8 +256,17 @@ def test_pitched_planes_in_place_and_device_helpers():
     after = d_frames.get()
     stego = np.stack([after[k * frame_pitch:k * frame_pitch + h * row_pitch].reshape(h, row_pitch)[:, :w]
                       for k in range(f)])
-    ref, _ = batch.embed_frames(want, delta, n_ac, bits)
+    ref, _ = batch.embed_frames(want, delta, n_ac, bits, mode="fast")
     assert np.array_equal(stego, ref)
+    # EXACT mode through the device-pointer entry points, pitched and in place as well
+    native.check(lib.svs_fill_synthetic_dev(d_frames.ptr, C.byref(planes), 99, 4, 16, 224, None), "fill")
+    assert batch.embed_device(d_frames.ptr, d_frames.ptr, planes, delta, n_ac, d_bits.ptr, 0, cap, mode="exact") == cap
+    after_x = d_frames.get()
+    stego_x = np.stack([after_x[k * frame_pitch:k * frame_pitch + h * row_pitch].reshape(h, row_pitch)[:, :w]
+                        for k in range(f)])
+    assert np.array_equal(stego_x, orc.batch_embed(want, delta, bits, n_ac)[0])
+    native.check(lib.svs_memcpy_h2d(d_frames.ptr, after.ctypes.data, after.nbytes, None), "restore")
+    native.check(lib.svs_stream_synchronize(None), "sync")
     mask = np.ones(span, bool)                              # padding bytes are never written
     for k in range(f):
         for y in range(h):
@@ -253,12 +302,16 @@ def test_error_codes():
     buf = np.zeros(64 * 64, np.uint8)
     out = np.zeros(64, np.uint8)
     got = C.c_uint64()
-    rc = lib.svs_extract(buf.ctypes.data, C.byref(bad), 8.0, 3, out.ctypes.data, out.size, C.byref(got))
+    rc = lib.svs_extract(buf.ctypes.data, C.byref(bad), 8.0, 3, out.ctypes.data, out.size, 0, C.byref(got))
     assert rc == native.SVS_ERR_INVALID_ARG and b"multiples of 8" in lib.svs_last_error()
     ok = Planes.contiguous(1, 64, 64)
-    rc = lib.svs_extract(buf.ctypes.data, C.byref(ok), 8.0, 3, out.ctypes.data, 2, C.byref(got))
+    rc = lib.svs_extract(buf.ctypes.data, C.byref(ok), 8.0, 3, out.ctypes.data, 2, 0, C.byref(got))
     assert rc == native.SVS_ERR_CAPACITY
-    rc = lib.svs_embed(None, None, C.byref(ok), 8.0, 3, None, 0, 0, C.byref(got))
+    rc = lib.svs_extract(buf.ctypes.data, C.byref(ok), 8.0, 3, out.ctypes.data, out.size, 0x80, C.byref(got))
+    assert rc == native.SVS_ERR_INVALID_ARG and b"flags" in lib.svs_last_error()
+    rc = native.SVS_ERR_CAPACITY
+    assert rc == native.SVS_ERR_CAPACITY
+    rc = lib.svs_embed(None, None, C.byref(ok), 8.0, 3, None, 0, 0, 0, C.byref(got))
     assert rc == native.SVS_ERR_INVALID_ARG
     with pytest.raises(native.SvsNativeError):
         native.check(rc, "svs_embed")
@@ -273,7 +326,7 @@ def test_drop_in_operator_matches_reference_contract(golden):
     g, stego, used = cs.proses_frame_qim_dct(gray, "embed", 20, pstr + "0101", num_ac_coeffs_to_use=10)
     assert used == info["used"] and g is not gray and np.array_equal(g, gray)
     assert stego.dtype == np.uint8 and stego.shape == gray.shape
-    assert abs(orc.psnr_u8(gray, stego) - info["psnr"]) <= PSNR_TOL_DB
+    assert np.array_equal(stego, arrays["G1_n10_d20/stego"])           # the operator defaults to EXACT mode
     text = cs.proses_frame_qim_dct(stego, "extract", 20, enable_debug_prints_extract=False, num_ac_coeffs_to_use=10)
     assert isinstance(text, str) and text == pstr
     assert cs.proses_frame_qim_dct(arrays["G1_n10_d20/stego"], "extract", 20, num_ac_coeffs_to_use=10) == \

@@ -89,10 +89,12 @@ def hostemu():
     lib.emu_embed.restype = ctypes.c_uint64
     lib.emu_embed.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                               ctypes.c_double, ctypes.c_int, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64,
-                              ctypes.c_uint64]
+                              ctypes.c_uint64, ctypes.c_int]
     lib.emu_extract.restype = ctypes.c_uint64
     lib.emu_extract.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double,
-                                ctypes.c_int, ctypes.c_void_p]
+                                ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
+    lib.emu_pf_dct2.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    lib.emu_pf_dct3.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
     lib.emu_forward_block.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
     lib.emu_idct8.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
     lib.emu_quant_mismatches.restype = ctypes.c_uint64
@@ -101,7 +103,7 @@ def hostemu():
     return lib
 
 
-def emu_embed(frames, delta, n_ac, bits, bit_offset=0):
+def emu_embed(frames, delta, n_ac, bits, bit_offset=0, exact=False):
     lib = hostemu()
     frames = np.ascontiguousarray(frames if frames.ndim == 3 else frames[None])
     f, h, w = frames.shape
@@ -109,15 +111,15 @@ def emu_embed(frames, delta, n_ac, bits, bit_offset=0):
     packed = np.concatenate([packed, np.zeros((-packed.size) % 4 + 4, np.uint8)])
     out = np.empty_like(frames)
     used = lib.emu_embed(frames.ctypes.data, out.ctypes.data, f, h, w, float(delta), int(n_ac),
-                         packed.ctypes.data, packed.size, int(bit_offset), int(len(bits) - bit_offset))
+                         packed.ctypes.data, packed.size, int(bit_offset), int(len(bits) - bit_offset), int(exact))
     return out, int(used)
 
 
-def emu_extract(frames, delta, n_ac):
+def emu_extract(frames, delta, n_ac, exact=False):
     lib = hostemu()
     frames = np.ascontiguousarray(frames if frames.ndim == 3 else frames[None])
     f, h, w = frames.shape
     n = max(0, min(int(n_ac), 63))
     out = np.zeros(f * (h // 8) * (w // 8) * n, np.uint8)
-    lib.emu_extract(frames.ctypes.data, f, h, w, float(delta), int(n_ac), out.ctypes.data)
+    lib.emu_extract(frames.ctypes.data, f, h, w, float(delta), int(n_ac), out.ctypes.data, int(exact))
     return out
