@@ -42,7 +42,7 @@ def parse_args():
     ap.add_argument("--width", type=int, default=3840)
     ap.add_argument("--n-ac", type=int, default=3)
     ap.add_argument("--delta", type=float, default=8.0)
-    ap.add_argument("--cpu-frames", type=int, default=6, help="frames in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-frames", type=int, default=96, help="frames in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--rehearse-gloo", action="store_true",
                     help="rank-logic rehearsal on a box with fewer GPUs than ranks: gloo backend, ranks share "
                          "GPUs, collectives staged through host memory (numbers are NOT bench results)")

@@ -234,8 +234,11 @@ __global__ __launch_bounds__(SVS_WG) void extract_kernel(const uint8_t *__restri
 // The embed kernel transforms all 64 coefficients both ways (about 2 700 VALU instructions per block),
 // so it is VALU-bound at roughly 40 % of the fast kernel's rate; it exists for bit-identical output.
 // ---------------------------------------------------------------------------------------
+#ifndef SVS_EXACT_MIN_WAVES
+#define SVS_EXACT_MIN_WAVES 4  // waves per SIMD the exact embed kernel is register-allocated for (4: +7 % over 3, 16-28 B of scratch)
+#endif
 template <int QM>
-__global__ __launch_bounds__(SVS_WG) void embed_exact_kernel(const uint8_t *__restrict__ gray,
+__global__ __launch_bounds__(SVS_WG, SVS_EXACT_MIN_WAVES) void embed_exact_kernel(const uint8_t *__restrict__ gray,
                                                           uint8_t *__restrict__ stego, const Geometry g,
                                                           const QimParams qp,
                                                           const uint32_t *__restrict__ bits,

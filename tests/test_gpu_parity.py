@@ -193,6 +193,59 @@ def test_full_size_round_trip_and_oracle_agreement(shape, n_ac, delta, frames):
                               orc.frame_extract_bits(ref_stego, delta, n_ac))
 
 
+@pytest.mark.parametrize("delta", [4, 8, 16])
+def test_baseline_config5_shape_8k_delta_sweep(delta):
+    """BASELINE.json configs[4]: 7680x4320, 3 AC coefficients, delta in {4, 8, 16}; one frame here
+    (the oracle needs seconds per 8K frame), PSNR and BER against the oracle on that frame."""
+    h, w, n_ac = 4320, 7680, 3
+    cover = synth.synthetic_frames(1, h, w, seed=delta)
+    cap = batch.capacity_bits(1, h, w, n_ac)
+    payload = synth.synthetic_bits(cap, seed=delta)
+    _, ref_stego, _ = orc.frame_embed(cover[0], delta, payload, n_ac)
+    ref_bits = orc.frame_extract_bits(ref_stego, delta, n_ac)
+    ref_ber = int((ref_bits != payload).sum())
+    assert (ref_ber == 0) == (delta >= 8)                     # SURVEY N5: only delta = 4 loses bits
+    # exact mode: everything identical
+    stego_x, used = batch.embed_frames(cover, delta, n_ac, payload, mode="exact")
+    assert used == cap and np.array_equal(stego_x[0], ref_stego)
+    # fast mode: same bits as the oracle on its own frames, same payload errors as the reference, same PSNR
+    stego, used = batch.embed_frames(cover, delta, n_ac, payload, mode="fast")
+    packed, n_bits = batch.extract_frames(stego, delta, n_ac, mode="fast")
+    got = np.unpackbits(packed, count=n_bits)
+    assert np.array_equal(got, orc.frame_extract_bits(stego[0], delta, n_ac))
+    assert abs(orc.psnr_u8(cover[0], stego[0]) - orc.psnr_u8(cover[0], ref_stego)) <= PSNR_TOL_DB
+    ber = int((got != payload).sum())
+    assert ber == 0 if delta >= 8 else abs(ber - ref_ber) <= 0.05 * ref_ber
+    _REPORT[f"8k_n3_d{delta}"] = {"pixels": h * w, "pixels_differing_from_reference": int((stego[0] != ref_stego).sum()),
+                                  "psnr": orc.psnr_u8(cover[0], stego[0]), "psnr_reference": orc.psnr_u8(cover[0], ref_stego),
+                                  "payload_bit_errors": ber, "payload_bit_errors_reference": ref_ber}
+
+
+def test_baseline_config4_shape_clips_sharded_by_frame():
+    """BASELINE.json configs[3]: 8 x 1080p clips, one per GPU, extracted bits gathered in rank order.  On the
+    one-GPU box the 8 shards run back to back through the same entry points the ranks use (shared payload
+    indexed by bit offset); the concatenation must equal the single-call result for the whole clip."""
+    h, w, n_ac, delta, world, frames_per_rank = 1080, 1920, 10, 8, 8, 2
+    total = world * frames_per_rank
+    cap = batch.capacity_bits(1, h, w, n_ac)
+    payload = synth.synthetic_bits(total * cap, seed=21)
+    whole = synth.synthetic_frames(total, h, w, seed=21)
+    stego_all, used_all = batch.embed_frames(whole, delta, n_ac, payload, mode="fast")
+    bits_all, n_all = batch.extract_frames(stego_all, delta, n_ac, mode="fast")
+    pieces = []
+    for rank in range(world):
+        first, count = batch.shard_frames(total, world, rank)
+        mine = synth.synthetic_frames(count, h, w, seed=21, first_frame=first)
+        stego, used = batch.embed_frames(mine, delta, n_ac, payload, bit_offset=first * cap, n_bits=count * cap,
+                                         mode="fast")
+        assert used == count * cap and np.array_equal(stego, stego_all[first:first + count])
+        packed, n_bits = batch.extract_frames(stego, delta, n_ac, mode="fast")
+        pieces.append(np.unpackbits(packed, count=n_bits))
+    joined = np.concatenate(pieces)
+    assert np.array_equal(joined, np.unpackbits(bits_all, count=n_all))
+    assert np.array_equal(joined, payload)
+
+
 def test_idempotent_and_deterministic():
     cover = synth.synthetic_frames(2, 64, 64, seed=1)
     payload = synth.synthetic_bits(2 * 64 * 5, seed=1)

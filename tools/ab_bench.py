@@ -16,9 +16,11 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--frames", type=int, default=600); ap.add_argument("--rounds", type=int, default=15)
 ap.add_argument("--n-ac", type=int, default=3); ap.add_argument("--delta", type=float, default=8.0)
 ap.add_argument("--h", type=int, default=2160); ap.add_argument("--w", type=int, default=3840)
+ap.add_argument("--mode", default="fast", choices=["fast", "exact"])
 ap.add_argument("--chunks", default="", help="comma list: sweep SVS_*_XCD_CHUNK on the first lib")
 ap.add_argument("libs", nargs="+")
 a = ap.parse_args()
+FLAGS = 1 if a.mode == "exact" else 0
 
 def load(path):
     lib = C.CDLL(os.path.abspath(path))
@@ -49,10 +51,10 @@ for r in range(a.rounds + 2):
             os.environ["SVS_EMBED_XCD_CHUNK"] = chunk; os.environ["SVS_EXTRACT_XCD_CHUNK"] = chunk
         e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
         e[0].record()
-        rc = lib.svs_embed_dev(gray.data_ptr(), stego.data_ptr(), C.byref(planes), a.delta, n, pay.data_ptr(), 0, cap, C.byref(done), st)
+        rc = lib.svs_embed_dev(gray.data_ptr(), stego.data_ptr(), C.byref(planes), a.delta, n, pay.data_ptr(), 0, cap, FLAGS, C.byref(done), st)
         assert rc == 0, lib.svs_last_error()
         e[1].record()
-        rc = lib.svs_extract_dev(stego.data_ptr(), C.byref(planes), a.delta, n, ext.data_ptr(), ext.numel(), C.byref(done), st)
+        rc = lib.svs_extract_dev(stego.data_ptr(), C.byref(planes), a.delta, n, ext.data_ptr(), ext.numel(), FLAGS, C.byref(done), st)
         assert rc == 0, lib.svs_last_error()
         e[2].record()
         torch.cuda.synchronize()
@@ -72,7 +74,7 @@ sink = torch.zeros(4096, dtype=torch.int32, device=dev)
 for r in range(a.rounds + 2):
     e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
     e[0].record()
-    assert libs[0][1].svs_embed_dev(gray.data_ptr(), stego.data_ptr(), C.byref(planes), a.delta, n, pay.data_ptr(), 0, 0, C.byref(done), st) == 0
+    assert libs[0][1].svs_embed_dev(gray.data_ptr(), stego.data_ptr(), C.byref(planes), a.delta, n, pay.data_ptr(), 0, 0, 0, C.byref(done), st) == 0
     e[1].record()
     stego.copy_(gray)
     e[2].record()

@@ -4,7 +4,7 @@ import collections, os, re, subprocess, sys
 repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(repo, "secure-video-steganography-using-ecc-and-dct_amd", "csrc", "svs_capi.hip")
 out = "/tmp/svs_isa.s"
-subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-ffp-contract=off", "-std=c++17", "--offload-arch=gfx950",
+subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-ffp-contract=off", "-fno-slp-vectorize", "-std=c++17", "--offload-arch=gfx950",
                 "-I" + os.path.join(repo, "include"), "-S", "--cuda-device-only", "-o", out, src]
                + [a for a in sys.argv[2:]], check=True, stderr=subprocess.DEVNULL)
 flt = sys.argv[1] if len(sys.argv) > 1 else ""

@@ -3,7 +3,7 @@
 import os, re, subprocess, sys
 repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(repo, "secure-video-steganography-using-ecc-and-dct_amd", "csrc", "svs_capi.hip")
-cmd = ["/opt/rocm/bin/hipcc", "-O3", "-ffp-contract=off", "-std=c++17", "-fPIC", "-shared", "--offload-arch=gfx950",
+cmd = ["/opt/rocm/bin/hipcc", "-O3", "-ffp-contract=off", "-fno-slp-vectorize", "-std=c++17", "-fPIC", "-shared", "--offload-arch=gfx950",
        "-I" + os.path.join(repo, "include"), "-Rpass-analysis=kernel-resource-usage",
        "-o", "/tmp/libsvsdct_report.so", src] + sys.argv[1:]
 out = subprocess.run(cmd, capture_output=True, text=True).stderr
