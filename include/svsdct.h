@@ -147,6 +147,14 @@ int svs_fill_bits_dev(uint8_t *d_bits_packed, uint64_t n_bits, uint32_t seed,
  * PSNR = 10 log10(255^2 H W / sse)   (cv2.PSNR as used at embed_process.py:205, app.py:342) */
 int svs_frame_sse_dev(const uint8_t *d_a, const uint8_t *d_b, const svs_planes *planes,
                       uint64_t *d_sse, void *stream);
+/* mean SSIM per frame -> d_ssim[n_frames] (double, device), as skimage.metrics.structural_similarity with its
+ * defaults for 2-D uint8 input (7x7 uniform window, K1 .01, K2 .03, sample covariance, float64) - the call
+ * behind the reference's evaluation.calc_ssim (evaluation.py:21-26).  d_data_range[n_frames] (double, device)
+ * gives skimage's data_range per frame; pass NULL to use the reference's quirk, max - min of frame b.
+ * d_workspace: at least svs_ssim_workspace_bytes(planes) bytes of device memory (8-byte aligned).  H, W >= 7. */
+uint64_t svs_ssim_workspace_bytes(const svs_planes *planes);
+int svs_frame_ssim_dev(const uint8_t *d_a, const uint8_t *d_b, const svs_planes *planes,
+                       const double *d_data_range, double *d_ssim, void *d_workspace, void *stream);
 /* number of differing bits among the first n_bits of two packed streams -> *d_count (uint64,
  * device, overwritten) */
 int svs_bit_errors_dev(const uint8_t *d_a_packed, const uint8_t *d_b_packed, uint64_t n_bits,

@@ -71,6 +71,15 @@ SVS_HD void fdct8(const float (&x)[8], float (&X)[8]) {
 // touched, config_and_setup.py:140).
 template <int NIN, bool SKIP0>
 SVS_HD void idct8(const float (&X)[8], float (&x)[8]) {
+    if constexpr (NIN == 2 && !SKIP0) {
+        // two inputs: evaluate the 8 outputs directly (1 mul + 8 fma) instead of butterflies (13 ops)
+        const float p = X[0] * SVS_A0;
+        x[0] = fmaf(X[1], SVS_C1, p); x[7] = fmaf(X[1], -SVS_C1, p);
+        x[1] = fmaf(X[1], SVS_C3, p); x[6] = fmaf(X[1], -SVS_C3, p);
+        x[2] = fmaf(X[1], SVS_C5, p); x[5] = fmaf(X[1], -SVS_C5, p);
+        x[3] = fmaf(X[1], SVS_C7, p); x[4] = fmaf(X[1], -SVS_C7, p);
+        return;
+    }
     float a, b;  // even part: DC and X4
     {
         const float p = SKIP0 ? 0.0f : X[0] * SVS_A0;

@@ -534,6 +534,41 @@ int svs_frame_sse_dev(const uint8_t *d_a, const uint8_t *d_b, const svs_planes *
     return SVS_OK;
 }
 
+uint64_t svs_ssim_workspace_bytes(const svs_planes *p) {
+    if (!p || p->n_frames <= 0 || p->height < 7 || p->width < 7) return 0;
+    const uint64_t gx = ((uint64_t)(p->width - 6) + 255) / 256, gy = ((uint64_t)(p->height - 6) + SVS_SSIM_BAND - 1) / SVS_SSIM_BAND;
+    return (gx * gy + 1) * (uint64_t)p->n_frames * sizeof(double);   // partials + one data_range per frame
+}
+
+int svs_frame_ssim_dev(const uint8_t *d_a, const uint8_t *d_b, const svs_planes *planes, const double *d_data_range,
+                       double *d_ssim, void *d_workspace, void *stream) {
+    svs::Geometry g;
+    uint64_t total = 0;
+    if (int rc = make_geometry(planes, 1, &g, &total)) return rc;
+    if (total == 0) return SVS_OK;
+    if (!d_a || !d_b || !d_ssim || !d_workspace) return fail(SVS_ERR_INVALID_ARG, "NULL pointer");
+    if (((uintptr_t)d_ssim % 8) || ((uintptr_t)d_workspace % 8)) return fail(SVS_ERR_INVALID_ARG, "pointers must be 8-byte aligned");
+    if (planes->n_frames > 65535) return fail(SVS_ERR_INVALID_ARG, "at most 65535 frames per call");
+    const hipStream_t st = (hipStream_t)stream;
+    const uint32_t gx = (uint32_t)(((uint64_t)(planes->width - 6) + 255) / 256);
+    const uint32_t gy = (uint32_t)(((uint64_t)(planes->height - 6) + SVS_SSIM_BAND - 1) / SVS_SSIM_BAND);
+    double *partial = reinterpret_cast<double *>(d_workspace);
+    double *range = partial + (uint64_t)gx * gy * planes->n_frames;
+    if (!d_data_range) {
+        hipLaunchKernelGGL(svs::frame_range_kernel, dim3((uint32_t)planes->n_frames), dim3(256), 0, st, d_b, planes->height,
+                           planes->width, planes->row_pitch, planes->frame_pitch, range);
+        SVS_HIP(hipGetLastError());
+        d_data_range = range;
+    }
+    hipLaunchKernelGGL(svs::ssim_partial_kernel, dim3(gx, gy, (uint32_t)planes->n_frames), dim3(256), 0, st, d_a, d_b,
+                       planes->height, planes->width, planes->row_pitch, planes->frame_pitch, d_data_range, partial);
+    SVS_HIP(hipGetLastError());
+    hipLaunchKernelGGL(svs::ssim_finish_kernel, dim3((uint32_t)planes->n_frames), dim3(64), 0, st, partial, (int32_t)(gx * gy),
+                       (double)(planes->width - 6) * (double)(planes->height - 6), d_ssim);
+    SVS_HIP(hipGetLastError());
+    return SVS_OK;
+}
+
 int svs_bit_errors_dev(const uint8_t *d_a_packed, const uint8_t *d_b_packed, uint64_t n_bits, uint64_t *d_count,
                        void *stream) {
     if (!d_count || ((uintptr_t)d_count % 8)) return fail(SVS_ERR_INVALID_ARG, "count pointer NULL or unaligned");

@@ -381,6 +381,108 @@ __global__ __launch_bounds__(256) void bit_errors_kernel(const uint8_t *__restri
     if ((threadIdx.x & 63u) == 0 && acc) atomicAdd(count, acc);
 }
 
+// ---------------------------------------------------------------------------------------
+// SSIM evaluator: mean structural similarity of two gray frames as
+// skimage.metrics.structural_similarity computes it with its defaults for 2-D uint8 input (what the
+// reference's evaluation.calc_ssim calls, evaluation.py:21-26): 7x7 uniform window, K1 = 0.01, K2 = 0.03,
+// sample covariance (NP/(NP-1)), float64 arithmetic, mean over the map cropped by 3 pixels per side.
+// Window sums are exact integers here (skimage's running float sums differ from them by rounding only).
+// One workgroup = 256 output columns x SSIM_BAND output rows; a thread walks down its column keeping the
+// last 7 horizontal window sums of the five moments in registers.
+// ---------------------------------------------------------------------------------------
+#define SVS_SSIM_BAND 64
+__global__ __launch_bounds__(256) void ssim_partial_kernel(const uint8_t *__restrict__ a, const uint8_t *__restrict__ b,
+                                                           int32_t height, int32_t width, int64_t row_pitch,
+                                                           int64_t frame_pitch, const double *__restrict__ data_range,
+                                                           double *__restrict__ partial) {
+    __shared__ uint8_t ra[256 + 6], rb[256 + 6];
+    __shared__ double red[4];
+    const int out_w = width - 6, out_h = height - 6;
+    const int x0 = blockIdx.x * 256, y0 = blockIdx.y * SVS_SSIM_BAND, f = blockIdx.z;
+    const int t = threadIdx.x;
+    const uint8_t *pa = a + (int64_t)f * frame_pitch, *pb = b + (int64_t)f * frame_pitch;
+    const double R = data_range[f];
+    const double C1 = (0.01 * R) * (0.01 * R), C2 = (0.03 * R) * (0.03 * R);
+    const double inv_np = 1.0 / 49.0, cov_norm = 49.0 / 48.0;
+    uint32_t ha[7], hb[7], haa[7], hbb[7], hab[7];  // ring of horizontal 7-sums, one entry per input row
+    uint32_t va = 0, vb = 0, vaa = 0, vbb = 0, vab = 0;
+#pragma unroll
+    for (int i = 0; i < 7; ++i) ha[i] = hb[i] = haa[i] = hbb[i] = hab[i] = 0;
+    double acc = 0.0;
+    const int rows = min(SVS_SSIM_BAND, out_h - y0) + 6;  // input rows this band touches
+    for (int r = 0; r < rows; ++r) {
+        const int y = y0 + r;
+        __syncthreads();
+        for (int i = t; i < 256 + 6; i += 256) {
+            const int x = x0 + i;
+            ra[i] = x < width ? pa[(int64_t)y * row_pitch + x] : 0;
+            rb[i] = x < width ? pb[(int64_t)y * row_pitch + x] : 0;
+        }
+        __syncthreads();
+        uint32_t sa = 0, sb = 0, saa = 0, sbb = 0, sab = 0;
+#pragma unroll
+        for (int d = 0; d < 7; ++d) {
+            const uint32_t u = ra[t + d], v = rb[t + d];
+            sa += u; sb += v; saa += u * u; sbb += v * v; sab += u * v;
+        }
+        // slide the vertical window: slot r % 7 holds the row that leaves
+#pragma unroll
+        for (int k = 0; k < 7; ++k) {
+            if (k == r % 7) {
+                va += sa - ha[k]; vb += sb - hb[k]; vaa += saa - haa[k]; vbb += sbb - hbb[k]; vab += sab - hab[k];
+                ha[k] = sa; hb[k] = sb; haa[k] = saa; hbb[k] = sbb; hab[k] = sab;
+            }
+        }
+        if (r >= 6 && x0 + t < out_w) {
+            const double ux = va * inv_np, uy = vb * inv_np;
+            const double vx = cov_norm * (vaa * inv_np - ux * ux), vy = cov_norm * (vbb * inv_np - uy * uy);
+            const double vxy = cov_norm * (vab * inv_np - ux * uy);
+            const double A1 = 2.0 * ux * uy + C1, A2 = 2.0 * vxy + C2, B1 = ux * ux + uy * uy + C1, B2 = vx + vy + C2;
+            acc += (A1 * A2) / (B1 * B2);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+    __syncthreads();
+    if ((t & 63) == 0) red[t >> 6] = acc;
+    __syncthreads();
+    if (t == 0)
+        partial[((int64_t)f * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// fixed-order sum of a frame's partials -> mean SSIM (deterministic: no atomics)
+__global__ void ssim_finish_kernel(const double *__restrict__ partial, int32_t per_frame, double count,
+                                   double *__restrict__ ssim) {
+    const int f = blockIdx.x;
+    if (threadIdx.x == 0) {
+        double s = 0.0;
+        for (int i = 0; i < per_frame; ++i) s += partial[(int64_t)f * per_frame + i];
+        ssim[f] = s / count;
+    }
+}
+
+// per-frame max - min of a plane (the data_range quirk of evaluation.calc_ssim, evaluation.py:26)
+__global__ __launch_bounds__(256) void frame_range_kernel(const uint8_t *__restrict__ a, int32_t height, int32_t width,
+                                                          int64_t row_pitch, int64_t frame_pitch,
+                                                          double *__restrict__ range) {
+    __shared__ uint32_t lo_s[4], hi_s[4];
+    const int f = blockIdx.x;
+    uint32_t lo = 255, hi = 0;
+    const uint64_t total = (uint64_t)height * width;
+    for (uint64_t i = threadIdx.x; i < total; i += 256) {
+        const uint32_t v = a[(int64_t)f * frame_pitch + (int64_t)(i / width) * row_pitch + (i % width)];
+        lo = min(lo, v); hi = max(hi, v);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { lo = min(lo, (uint32_t)__shfl_down(lo, o, 64)); hi = max(hi, (uint32_t)__shfl_down(hi, o, 64)); }
+    if ((threadIdx.x & 63) == 0) { lo_s[threadIdx.x >> 6] = lo; hi_s[threadIdx.x >> 6] = hi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int i = 1; i < 4; ++i) { lo = min(lo, lo_s[i]); hi = max(hi, hi_s[i]); }
+        range[f] = (double)hi - (double)lo;
+    }
+}
+
 // ---- reference streams for tools/ab_bench.py: what plain copies / reads reach on the same box ----
 // mode 0: one 16-byte element per thread, non-temporal;  mode 1: grid-stride, 4 x 16 B in flight per
 // thread, non-temporal;  mode 2: as 1 with default cache policy

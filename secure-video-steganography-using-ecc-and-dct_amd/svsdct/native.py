@@ -63,6 +63,8 @@ SIGNATURES = {
     "svs_fill_synthetic_dev": (C.c_int, [_u8p, _PL, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]),
     "svs_fill_bits_dev": (C.c_int, [_u8p, C.c_uint64, C.c_uint32, C.c_uint64, C.c_void_p]),
     "svs_frame_sse_dev": (C.c_int, [_u8p, _u8p, _PL, C.c_void_p, C.c_void_p]),
+    "svs_ssim_workspace_bytes": (C.c_uint64, [_PL]),
+    "svs_frame_ssim_dev": (C.c_int, [_u8p, _u8p, _PL, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "svs_bit_errors_dev": (C.c_int, [_u8p, _u8p, C.c_uint64, C.c_void_p, C.c_void_p]),
 }
 

@@ -349,6 +349,30 @@ def test_pitched_planes_in_place_and_device_helpers():
     assert np.array_equal(sse.astype(np.int64), want_sse)
 
 
+def test_device_psnr_and_ssim_evaluators():
+    """SURVEY 8(f) rank 3: per-frame PSNR / SSIM on device against the CPU restatements (oracle/metrics_oracle.py;
+    SSIM restates skimage's algorithm - skimage itself is not installed, so that leg is parity-unpinned)."""
+    from oracle import metrics_oracle as mo
+    from svsdct import metrics
+    f, h, w = 3, 200, 328
+    cover = synth.synthetic_frames(f, h, w, seed=8)
+    cover[1] = (np.add.outer(np.arange(h), np.arange(w)) % 256).astype(np.uint8)      # smooth content
+    cover[2, :100] = 77                                                                # flat area
+    stego, _ = batch.embed_frames(cover, 12, 10, synth.synthetic_bits(batch.capacity_bits(f, h, w, 10), seed=8),
+                                  mode="fast")
+    planes = Planes.contiguous(f, h, w)
+    d_a, d_b = _Dev(cover.nbytes), _Dev(stego.nbytes)
+    d_a.put(cover)
+    d_b.put(stego)
+    for data_range in (255.0, None):
+        psnr, ssim = metrics.psnr_ssim_device(d_a.ptr, d_b.ptr, planes, data_range)
+        for k in range(f):
+            assert abs(psnr[k] - mo.psnr_cv2(cover[k], stego[k])) < 1e-9
+            assert abs(ssim[k] - mo.ssim_skimage(cover[k], stego[k], data_range)) < 1e-9, (k, data_range)
+    psnr, ssim = metrics.psnr_ssim_device(d_a.ptr, d_a.ptr, planes)
+    assert np.isinf(psnr).all() and np.allclose(ssim, 1.0)
+
+
 def test_error_codes():
     lib = native.load()
     bad = Planes(1, 12, 16, 0, 16, 12 * 16)
