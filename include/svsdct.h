@@ -135,6 +135,19 @@ int svs_extract(const uint8_t *gray, const svs_planes *planes, double delta, int
                 uint8_t *bits_packed_out, uint64_t out_capacity_bytes, uint32_t flags,
                 uint64_t *n_bits_out);
 
+/* ---- colour plumbing around the operator (device resident) --------------------------------------------
+ * Interleaved 8-bit BGR frames [frame][row][col][3] <-> gray planes.  bgr_row_pitch / bgr_frame_pitch in bytes,
+ * multiples of 4; BGR base pointers 4-byte aligned.
+ * svs_bgr_to_gray_dev replaces cv2.cvtColor(frame, COLOR_BGR2GRAY) (config_and_setup.py:112): OpenCV's fixed-point
+ * (B*wb + G*wg + R*wr + 2^(shift-1)) >> shift.  weights = {wb, wg, wr, shift}; NULL = {3735, 19235, 9798, 15}
+ * (OpenCV 4's 15-bit table; older builds use {1868, 9617, 4899, 14}).  Parity with cv2 is UNPINNED (cv2 is not
+ * available in the build image) - a caller that has cv2 should compare once at start-up.
+ * svs_gray_to_bgr_dev replaces cv2.cvtColor(stego, COLOR_GRAY2BGR) (embed_process.py:126): B = G = R = gray. */
+int svs_bgr_to_gray_dev(const uint8_t *d_bgr, int64_t bgr_row_pitch, int64_t bgr_frame_pitch, uint8_t *d_gray,
+                        const svs_planes *planes, const uint32_t *weights, void *stream);
+int svs_gray_to_bgr_dev(const uint8_t *d_gray, const svs_planes *planes, uint8_t *d_bgr, int64_t bgr_row_pitch,
+                        int64_t bgr_frame_pitch, void *stream);
+
 /* ---- measurement helpers (synthetic inputs and on-device checks for bench.py / tests) ------ */
 /* value = lo + hash32(seed, first_frame + f, y, x) % span  - same hash as svsdct/synth.py */
 int svs_fill_synthetic_dev(uint8_t *d_frames, const svs_planes *planes, uint32_t seed,

@@ -65,16 +65,16 @@ def bitstream_ke_int(bitstream_nilai: str, jumlah_bit_diharapkan=None) -> int:
 # ------------------------------------------------------------------------------------------
 def _bgr_to_gray(frame_bgr: np.ndarray) -> np.ndarray:
     """cv2.cvtColor(frame, COLOR_BGR2GRAY) (reference :112).  Uses OpenCV when it is installed so
-    that the gray plane is the reference's; otherwise OpenCV's documented fixed-point BT.601
-    weights (R 4899, G 9617, B 1868, >> 14, round half up) - parity of this branch is unpinned
-    because cv2 is absent from the build image."""
+    that the gray plane is the reference's; otherwise OpenCV 4's fixed-point BT.601 table
+    (B 3735, G 19235, R 9798, + 2^14, >> 15 - the default of svs_bgr_to_gray_dev as well).  Parity of
+    this branch is unpinned because cv2 is absent from the build image."""
     try:
         import cv2  # noqa: WPS433 (lazy on purpose)
     except ImportError:
         b = frame_bgr[..., 0].astype(np.uint32)
         g = frame_bgr[..., 1].astype(np.uint32)
         r = frame_bgr[..., 2].astype(np.uint32)
-        return ((b * 1868 + g * 9617 + r * 4899 + 8192) >> 14).astype(np.uint8)
+        return ((b * 3735 + g * 19235 + r * 9798 + 16384) >> 15).astype(np.uint8)
     return cv2.cvtColor(frame_bgr, cv2.COLOR_BGR2GRAY)
 
 

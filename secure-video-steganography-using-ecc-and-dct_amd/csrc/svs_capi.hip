@@ -490,6 +490,47 @@ int svs_extract(const uint8_t *gray, const svs_planes *planes, double delta, int
     return SVS_OK;
 }
 
+static int check_bgr(const svs_planes *p, const void *bgr, int64_t rp, int64_t fp) {
+    if (!bgr || ((uintptr_t)bgr % 4)) return fail(SVS_ERR_INVALID_ARG, "BGR pointer NULL or not 4-byte aligned");
+    if (rp < 3 * (int64_t)p->width || (rp % 4) || fp < rp * p->height || (fp % 4))
+        return fail(SVS_ERR_INVALID_ARG, "BGR pitches must cover 3*width bytes per row and be multiples of 4");
+    return SVS_OK;
+}
+
+int svs_bgr_to_gray_dev(const uint8_t *d_bgr, int64_t bgr_row_pitch, int64_t bgr_frame_pitch, uint8_t *d_gray,
+                        const svs_planes *planes, const uint32_t *weights, void *stream) {
+    svs::Geometry g;
+    uint64_t total = 0;
+    if (int rc = make_geometry(planes, 1, &g, &total)) return rc;
+    if (total == 0) return SVS_OK;
+    if (!d_gray || ((uintptr_t)d_gray % 8)) return fail(SVS_ERR_INVALID_ARG, "gray pointer NULL or unaligned");
+    if (int rc = check_bgr(planes, d_bgr, bgr_row_pitch, bgr_frame_pitch)) return rc;
+    const uint32_t dflt[4] = {3735u, 19235u, 9798u, 15u};
+    const uint32_t *w = weights ? weights : dflt;
+    if (w[3] < 1 || w[3] > 16 || w[0] + w[1] + w[2] != (1u << w[3]))
+        return fail(SVS_ERR_INVALID_ARG, "weights must sum to 2^shift with 1 <= shift <= 16");
+    hipLaunchKernelGGL(svs::bgr_to_gray_kernel, dim3(8192), dim3(256), 0, (hipStream_t)stream, d_bgr, d_gray,
+                       planes->n_frames, planes->height, planes->width, bgr_row_pitch, bgr_frame_pitch,
+                       planes->row_pitch, planes->frame_pitch, w[0], w[1], w[2], w[3]);
+    SVS_HIP(hipGetLastError());
+    return SVS_OK;
+}
+
+int svs_gray_to_bgr_dev(const uint8_t *d_gray, const svs_planes *planes, uint8_t *d_bgr, int64_t bgr_row_pitch,
+                        int64_t bgr_frame_pitch, void *stream) {
+    svs::Geometry g;
+    uint64_t total = 0;
+    if (int rc = make_geometry(planes, 1, &g, &total)) return rc;
+    if (total == 0) return SVS_OK;
+    if (!d_gray || ((uintptr_t)d_gray % 8)) return fail(SVS_ERR_INVALID_ARG, "gray pointer NULL or unaligned");
+    if (int rc = check_bgr(planes, d_bgr, bgr_row_pitch, bgr_frame_pitch)) return rc;
+    hipLaunchKernelGGL(svs::gray_to_bgr_kernel, dim3(8192), dim3(256), 0, (hipStream_t)stream, d_gray, d_bgr,
+                       planes->n_frames, planes->height, planes->width, planes->row_pitch, planes->frame_pitch,
+                       bgr_row_pitch, bgr_frame_pitch);
+    SVS_HIP(hipGetLastError());
+    return SVS_OK;
+}
+
 int svs_fill_synthetic_dev(uint8_t *d_frames, const svs_planes *planes, uint32_t seed, uint32_t first_frame,
                            uint32_t lo, uint32_t span, void *stream) {
     svs::Geometry g;

@@ -382,6 +382,56 @@ __global__ __launch_bounds__(256) void bit_errors_kernel(const uint8_t *__restri
 }
 
 // ---------------------------------------------------------------------------------------
+// Colour plumbing around the operator: interleaved 8-bit BGR -> gray
+// (cv2.COLOR_BGR2GRAY, config_and_setup.py:112) and gray -> BGR (cv2.COLOR_GRAY2BGR, embed_process.py:126).
+// OpenCV's 8-bit BGR2GRAY is fixed point: (B*wb + G*wg + R*wr + 2^(shift-1)) >> shift; the weights are passed
+// in because they differ between OpenCV generations (15-bit 3735/19235/9798 today, 14-bit 1868/9617/4899 in
+// older builds) and cv2 is not available to pin either.  4 pixels per thread: 12 bytes in, one dword out.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bgr_to_gray_kernel(const uint8_t *__restrict__ bgr, uint8_t *__restrict__ gray,
+                                                          int32_t n_frames, int32_t height, int32_t width,
+                                                          int64_t bgr_row_pitch, int64_t bgr_frame_pitch,
+                                                          int64_t row_pitch, int64_t frame_pitch, uint32_t wb,
+                                                          uint32_t wg, uint32_t wr, uint32_t shift) {
+    const uint32_t quads = (uint32_t)width / 4u;
+    const uint64_t total = (uint64_t)n_frames * height * quads;
+    const uint32_t half = 1u << (shift - 1);
+    for (uint64_t t = (uint64_t)blockIdx.x * 256u + threadIdx.x; t < total; t += (uint64_t)gridDim.x * 256u) {
+        const uint32_t xq = (uint32_t)(t % quads);
+        const uint64_t r = t / quads;
+        const uint32_t y = (uint32_t)(r % (uint32_t)height), f = (uint32_t)(r / (uint32_t)height);
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(bgr + (int64_t)f * bgr_frame_pitch +
+                                                                 (int64_t)y * bgr_row_pitch + 12u * xq);
+        const uint32_t w0 = src[0], w1 = src[1], w2 = src[2];  // B0 G0 R0 B1 | G1 R1 B2 G2 | R2 B3 G3 R3
+        const uint32_t p0 = ((w0 & 0xff) * wb + ((w0 >> 8) & 0xff) * wg + ((w0 >> 16) & 0xff) * wr + half) >> shift;
+        const uint32_t p1 = ((w0 >> 24) * wb + (w1 & 0xff) * wg + ((w1 >> 8) & 0xff) * wr + half) >> shift;
+        const uint32_t p2 = (((w1 >> 16) & 0xff) * wb + (w1 >> 24) * wg + (w2 & 0xff) * wr + half) >> shift;
+        const uint32_t p3 = (((w2 >> 8) & 0xff) * wb + ((w2 >> 16) & 0xff) * wg + (w2 >> 24) * wr + half) >> shift;
+        *reinterpret_cast<uint32_t *>(gray + (int64_t)f * frame_pitch + (int64_t)y * row_pitch + 4u * xq) =
+            p0 | (p1 << 8) | (p2 << 16) | (p3 << 24);
+    }
+}
+
+__global__ __launch_bounds__(256) void gray_to_bgr_kernel(const uint8_t *__restrict__ gray, uint8_t *__restrict__ bgr,
+                                                          int32_t n_frames, int32_t height, int32_t width,
+                                                          int64_t row_pitch, int64_t frame_pitch,
+                                                          int64_t bgr_row_pitch, int64_t bgr_frame_pitch) {
+    const uint32_t quads = (uint32_t)width / 4u;
+    const uint64_t total = (uint64_t)n_frames * height * quads;
+    for (uint64_t t = (uint64_t)blockIdx.x * 256u + threadIdx.x; t < total; t += (uint64_t)gridDim.x * 256u) {
+        const uint32_t xq = (uint32_t)(t % quads);
+        const uint64_t r = t / quads;
+        const uint32_t y = (uint32_t)(r % (uint32_t)height), f = (uint32_t)(r / (uint32_t)height);
+        const uint32_t g = *reinterpret_cast<const uint32_t *>(gray + (int64_t)f * frame_pitch + (int64_t)y * row_pitch + 4u * xq);
+        const uint32_t a = g & 0xff, b = (g >> 8) & 0xff, c = (g >> 16) & 0xff, d = g >> 24;
+        uint32_t *dst = reinterpret_cast<uint32_t *>(bgr + (int64_t)f * bgr_frame_pitch + (int64_t)y * bgr_row_pitch + 12u * xq);
+        dst[0] = a * 0x010101u | (b << 24);
+        dst[1] = b * 0x0101u | (c * 0x0101u << 16);
+        dst[2] = c | (d * 0x010101u << 8);
+    }
+}
+
+// ---------------------------------------------------------------------------------------
 // SSIM evaluator: mean structural similarity of two gray frames as
 // skimage.metrics.structural_similarity computes it with its defaults for 2-D uint8 input (what the
 // reference's evaluation.calc_ssim calls, evaluation.py:21-26): 7x7 uniform window, K1 = 0.01, K2 = 0.03,

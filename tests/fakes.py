@@ -56,7 +56,7 @@ def make_fake_cv2():
     def cvtColor(img, code):
         if code == cv2.COLOR_BGR2GRAY:       # OpenCV's fixed-point BT.601
             b, g, r = (img[..., i].astype(np.uint32) for i in range(3))
-            return ((b * 1868 + g * 9617 + r * 4899 + 8192) >> 14).astype(np.uint8)
+            return ((b * 3735 + g * 19235 + r * 9798 + 16384) >> 15).astype(np.uint8)
         if code == cv2.COLOR_GRAY2BGR:
             return np.repeat(img[..., None], 3, axis=2)
         raise NotImplementedError(code)

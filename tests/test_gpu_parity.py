@@ -373,6 +373,37 @@ def test_device_psnr_and_ssim_evaluators():
     assert np.isinf(psnr).all() and np.allclose(ssim, 1.0)
 
 
+def test_device_colour_conversions():
+    """BGR -> gray (OpenCV fixed-point formula, both weight tables) and gray -> BGR on device."""
+    lib = native.load()
+    rng = np.random.default_rng(3)
+    f, h, w = 2, 24, 40
+    bgr = rng.integers(0, 256, (f, h, w, 3), dtype=np.uint8)
+    bgr[0, 0, :4] = [[255, 255, 255], [0, 0, 0], [255, 0, 0], [0, 0, 255]]
+    planes = Planes.contiguous(f, h, w)
+    d_bgr, d_gray, d_back = _Dev(bgr.nbytes), _Dev(f * h * w), _Dev(bgr.nbytes)
+    d_bgr.put(bgr)
+    b, g, r = (bgr[..., i].astype(np.uint32) for i in range(3))
+    for weights, want in ((None, (b * 3735 + g * 19235 + r * 9798 + 16384) >> 15),
+                          (np.array([1868, 9617, 4899, 14], np.uint32), (b * 1868 + g * 9617 + r * 4899 + 8192) >> 14)):
+        wp = weights.ctypes.data if weights is not None else None
+        native.check(lib.svs_bgr_to_gray_dev(d_bgr.ptr, 3 * w, 3 * w * h, d_gray.ptr, C.byref(planes), wp, None), "bgr2gray")
+        assert np.array_equal(d_gray.get().reshape(f, h, w), want.astype(np.uint8))
+    import config_and_setup as cs
+    assert np.array_equal(cs._bgr_to_gray(bgr[0]), d_gray_default(bgr[0]))
+    native.check(lib.svs_gray_to_bgr_dev(d_gray.ptr, C.byref(planes), d_back.ptr, 3 * w, 3 * w * h, None), "gray2bgr")
+    back = d_back.get().reshape(f, h, w, 3)
+    assert np.array_equal(back, np.repeat(d_gray.get().reshape(f, h, w)[..., None], 3, axis=3))
+    bad = np.array([1, 2, 3, 15], np.uint32)
+    assert lib.svs_bgr_to_gray_dev(d_bgr.ptr, 3 * w, 3 * w * h, d_gray.ptr, C.byref(planes), bad.ctypes.data, None) == \
+        native.SVS_ERR_INVALID_ARG
+
+
+def d_gray_default(frame_bgr):
+    b, g, r = (frame_bgr[..., i].astype(np.uint32) for i in range(3))
+    return ((b * 3735 + g * 19235 + r * 9798 + 16384) >> 15).astype(np.uint8)
+
+
 def test_error_codes():
     lib = native.load()
     bad = Planes(1, 12, 16, 0, 16, 12 * 16)
