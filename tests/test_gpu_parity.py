@@ -246,6 +246,33 @@ def test_baseline_config4_shape_clips_sharded_by_frame():
     assert np.array_equal(joined, payload)
 
 
+def test_random_geometries_match_the_cpu_build_of_the_kernel_header():
+    """Indexing check over many shapes: odd block counts per row (no 16-byte path), partial waves and tiles, budgets
+    ending mid-block, bit offsets, all coefficient-row counts.  The GPU must produce exactly what the CPU build of
+    csrc/svs_block.hpp produces (fast mode) and what the oracle produces (exact mode)."""
+    rng = np.random.default_rng(2025)
+    for it in range(40):
+        f = int(rng.integers(1, 6))
+        h, w = 8 * int(rng.integers(1, 18)), 8 * int(rng.integers(1, 40))
+        n_ac = int(rng.integers(1, 64))
+        delta = [2, 4, 8, 20, 7.5, 13][it % 6]
+        cap = batch.capacity_bits(f, h, w, n_ac)
+        off = int(rng.integers(0, 97))
+        n_bits = int(rng.integers(0, cap + 20))
+        bits = rng.integers(0, 2, off + n_bits).astype(np.uint8)
+        frames = rng.integers(0, 256, (f, h, w), dtype=np.uint8)
+        stego, used = batch.embed_frames(frames, delta, n_ac, bits, bit_offset=off, n_bits=n_bits, mode="fast")
+        want, want_used = emu_embed(frames, delta, n_ac, bits, bit_offset=off)
+        assert used == want_used == min(n_bits, cap) and np.array_equal(stego, want), (it, f, h, w, n_ac, delta)
+        packed, n = batch.extract_frames(stego, delta, n_ac, mode="fast")
+        assert np.array_equal(np.unpackbits(packed, count=n), emu_extract(stego, delta, n_ac)), (it, f, h, w, n_ac)
+        stego_x, used_x = batch.embed_frames(frames, delta, n_ac, bits, bit_offset=off, n_bits=n_bits, mode="exact")
+        ref, ref_used = orc.batch_embed(frames, delta, bits[off:], n_ac)
+        assert used_x == ref_used and np.array_equal(stego_x, ref), (it, f, h, w, n_ac, delta)
+        packed, n = batch.extract_frames(frames, delta, n_ac, mode="exact")
+        assert np.array_equal(np.unpackbits(packed, count=n), orc.batch_extract_bits(frames, delta, n_ac))
+
+
 def test_idempotent_and_deterministic():
     cover = synth.synthetic_frames(2, 64, 64, seed=1)
     payload = synth.synthetic_bits(2 * 64 * 5, seed=1)
