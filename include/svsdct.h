@@ -88,6 +88,12 @@ int svs_memcpy_h2d(void *dev_dst, const void *host_src, size_t bytes, void *stre
 int svs_memcpy_d2h(void *host_dst, const void *dev_src, size_t bytes, void *stream);
 int svs_memset(void *dev_dst, int value, size_t bytes, void *stream);
 int svs_stream_synchronize(void *stream);
+/* Streams and pinned (page-locked) host memory for callers that overlap frame I/O with the kernels
+ * (svsdct/pipeline.py): copies to/from pinned memory run asynchronously and at full link rate. */
+int svs_stream_create(void **stream);
+int svs_stream_destroy(void *stream);
+int svs_host_alloc(void **host_ptr, size_t bytes);
+int svs_host_free(void *host_ptr);
 
 /* ---- capacity arithmetic ------------------------------------------------------------------ */
 /* bits one batch carries: n_frames * (H/8) * (W/8) * clamp(n_ac, 0, 63) */

@@ -296,6 +296,31 @@ int svs_stream_synchronize(void *stream) {
     return SVS_OK;
 }
 
+int svs_stream_create(void **stream) {
+    if (!stream) return fail(SVS_ERR_INVALID_ARG, "stream is NULL");
+    hipStream_t st = nullptr;
+    SVS_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    *stream = st;
+    return SVS_OK;
+}
+
+int svs_stream_destroy(void *stream) {
+    SVS_HIP(hipStreamDestroy((hipStream_t)stream));
+    return SVS_OK;
+}
+
+int svs_host_alloc(void **host_ptr, size_t bytes) {
+    if (!host_ptr) return fail(SVS_ERR_INVALID_ARG, "host_ptr is NULL");
+    *host_ptr = nullptr;
+    SVS_HIP(hipHostMalloc(host_ptr, bytes ? bytes : 4, hipHostMallocDefault));
+    return SVS_OK;
+}
+
+int svs_host_free(void *host_ptr) {
+    SVS_HIP(hipHostFree(host_ptr));
+    return SVS_OK;
+}
+
 uint64_t svs_capacity_bits(const svs_planes *p, int n_ac) {
     if (!p || p->n_frames <= 0 || p->height <= 0 || p->width <= 0) return 0;
     return (uint64_t)p->n_frames * (uint64_t)(p->height / 8) * (uint64_t)(p->width / 8) * (uint64_t)clamp_ac(n_ac);

@@ -54,6 +54,10 @@ SIGNATURES = {
     "svs_memcpy_d2h": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "svs_memset": (C.c_int, [C.c_void_p, C.c_int, C.c_size_t, C.c_void_p]),
     "svs_stream_synchronize": (C.c_int, [C.c_void_p]),
+    "svs_stream_create": (C.c_int, [C.POINTER(C.c_void_p)]),
+    "svs_stream_destroy": (C.c_int, [C.c_void_p]),
+    "svs_host_alloc": (C.c_int, [C.POINTER(C.c_void_p), C.c_size_t]),
+    "svs_host_free": (C.c_int, [C.c_void_p]),
     "svs_capacity_bits": (C.c_uint64, [_PL, C.c_int]),
     "svs_packed_bytes": (C.c_uint64, [C.c_uint64]),
     "svs_embed_dev": (C.c_int, [_u8p, _u8p, _PL, C.c_double, C.c_int, _u8p, C.c_uint64, C.c_uint64, C.c_uint32, _u64p, C.c_void_p]),

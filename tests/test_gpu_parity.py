@@ -431,6 +431,38 @@ def d_gray_default(frame_bgr):
     return ((b * 3735 + g * 19235 + r * 9798 + 16384) >> 15).astype(np.uint8)
 
 
+def test_overlapped_host_pipeline_equals_one_shot_calls():
+    """pinned, multi-stream staging (svsdct/pipeline.py) must give the frames / bits of the plain
+    host-array calls, batch after batch, including a short last batch and a payload that ends mid-clip."""
+    from svsdct.pipeline import FramePipeline
+    h, w, n_ac, delta, per_batch, n_frames = 64, 96, 5, 8, 4, 14
+    clip = synth.synthetic_frames(n_frames, h, w, seed=31)
+    cap1 = batch.capacity_bits(1, h, w, n_ac)
+    payload = synth.synthetic_bits(cap1 * 9 + 11, seed=31)                 # ends inside frame 9
+    want, used = batch.embed_frames(clip, delta, n_ac, payload, mode="fast")
+    want_bits, n_all = batch.extract_frames(want, delta, n_ac, mode="fast")
+    with FramePipeline(h, w, per_batch, delta, n_ac, depth=3) as pipe:
+        pipe.set_payload(payload)
+        batches = [clip[i:i + per_batch] for i in range(0, n_frames, per_batch)]
+        got, carried = [None] * len(batches), 0
+        for k, frames in enumerate(batches + [None] * pipe.depth):
+            slot = k % pipe.depth
+            if k >= pipe.depth:
+                got[k - pipe.depth] = pipe.embed_result(slot).copy()
+            if frames is not None:
+                np.copyto(pipe.input(slot)[:len(frames)], frames)
+                carried += pipe.submit_embed(slot, len(frames), bit_offset=k * pipe.batch_capacity)
+        stego = np.concatenate(got)
+        assert carried == used == payload.size and np.array_equal(stego, want)
+        streams = []
+        for k, frames in enumerate([stego[i:i + per_batch] for i in range(0, n_frames, per_batch)]):
+            np.copyto(pipe.input(0)[:len(frames)], frames)
+            pipe.submit_extract(0, len(frames))
+            packed, n = pipe.extract_result(0)
+            streams.append(np.unpackbits(packed, count=n))
+        assert np.array_equal(np.concatenate(streams), np.unpackbits(want_bits, count=n_all))
+
+
 def test_error_codes():
     lib = native.load()
     bad = Planes(1, 12, 16, 0, 16, 12 * 16)
