@@ -53,6 +53,7 @@ int clamp_ac(int n_ac) { return n_ac < 0 ? 0 : (n_ac > 63 ? 63 : n_ac); }
 // validates the plane description and fills the kernel geometry
 int make_geometry(const svs_planes *p, int n_ac, svs::Geometry *g, uint64_t *total_blocks) {
     if (!p) return fail(SVS_ERR_INVALID_ARG, "planes is NULL");
+    if (p->reserved != 0) return fail(SVS_ERR_INVALID_ARG, "svs_planes.reserved must be 0");
     if (p->n_frames < 0 || p->height <= 0 || p->width <= 0)
         return fail(SVS_ERR_INVALID_ARG, "bad frame geometry %d x %d x %d", p->n_frames, p->height, p->width);
     if ((p->height % 8) || (p->width % 8))
