@@ -222,8 +222,19 @@ def main():
     psnr0 = float("inf") if sse0 == 0 else 10 * math.log10(255.0 ** 2 * H * W / sse0)
     gather_ok = None
     if use_dist and rank == 0:
-        # rank 0's own slice of the gathered stream must be what it extracted
-        gather_ok = bool(torch.equal(gathered[last][0].to(dev), extracted[:nbytes]))
+        # the gathered stream on rank 0: slice r must be rank r's payload (regenerated here from the counter-based
+        # generator), i.e. the reassembled global bit stream is correct and in rank order
+        expect = torch.zeros_like(payload)
+        wrong = 0
+        for r in range(world):
+            native.check(lib.svs_fill_bits_dev(expect.data_ptr(), cap, SEED, r * cap, stream), "fill_bits")
+            piece = gathered[last][r].to(dev)
+            padded = torch.zeros_like(payload)
+            padded[:nbytes] = piece
+            native.check(lib.svs_bit_errors_dev(padded.data_ptr(), expect.data_ptr(), cap, cnt.data_ptr(), stream), "ber")
+            torch.cuda.synchronize()
+            wrong += int(cnt.item())
+        gather_ok = bool(wrong == 0 and torch.equal(gathered[last][0].to(dev), extracted[:nbytes]))
 
     result = None
     if rank == 0:
@@ -261,7 +272,7 @@ def main():
                          "extract_achieved": extract_bytes / (extract_ms * 1e-3) / 1e9},
         }
         if gather_ok is not None:
-            result["gather_ok"] = gather_ok
+            result["gather_ok"] = gather_ok      # every rank's slice of the gathered stream equals its payload
 
     # ---- EXACT mode (pocketfft-identical arithmetic) timed on the same batch, reported beside the headline ------
     if rank == 0:
