@@ -36,8 +36,8 @@ SEED = 20250620
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--frames", type=int, default=600, help="frames per GPU per step")
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--width", type=int, default=3840)
