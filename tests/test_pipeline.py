@@ -131,6 +131,30 @@ def test_payload_spread_over_many_frames_and_batches(monkeypatch, tmp_path, back
 
 
 @pytest.mark.parametrize("backend", BACKENDS)
+def test_reference_dummy_configuration(monkeypatch, tmp_path, backend):
+    """BASELINE.json configs[0]: the reference's own dummy inputs (config_and_setup.py:225,232-233; defaults
+    embed_process.py:169-170) - 640x480 uniform-noise colour clip, 32x32 'lightgray' secret, delta 20, 10 coefficients.
+    9 168 payload bits fit in the first frame (capacity 48 000); every other frame is copied in colour."""
+    emb, ext = _install(monkeypatch, backend)
+    rng = np.random.default_rng(0)
+    frames = [rng.integers(0, 256, (480, 640, 3), dtype=np.uint8) for _ in range(4)]      # 4 of the 120 frames
+    fakes.VIDEOS["cover.mp4"] = {"frames": frames, "fps": 24.0}
+    secret_path = str(tmp_path / "rahasia.png")
+    Image.new("L", (32, 32), color="lightgray").save(secret_path)
+    receiver = fakes.FakeKey(b"bob")
+    pub = fakes.serialisasi_kunci_publik_ecc_compressed(receiver.public())
+    ok, g0, s0 = emb.embed_gambar_ke_video_final("cover.mp4", secret_path, str(tmp_path / "stego_video_final"), 20, 10, pub)
+    assert ok and g0.shape == (480, 640)
+    out = fakes.VIDEOS[str(tmp_path / "stego_video_final.avi")]["frames"]
+    assert len(out) == 4 and all(np.array_equal(out[k], frames[k]) for k in (1, 2, 3))
+    psnr = orc.psnr_u8(g0, s0)
+    assert 30 < psnr < 60                                         # "BAIK" by the reference's own threshold
+    assert ext.ekstraksi_gambar_video_final(str(tmp_path / "stego_video_final.avi"), str(tmp_path / "hasil.png"), 20, 10,
+                                            receiver)
+    assert (np.asarray(Image.open(str(tmp_path / "hasil.png"))) == 211).all()          # 'lightgray' in mode L
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
 def test_failure_exits(monkeypatch, tmp_path, capsys, backend):
     emb, ext = _install(monkeypatch, backend)
     frames, secret, secret_path = _make_inputs(tmp_path, n_frames=1, size=(72, 96))
