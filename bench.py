@@ -321,8 +321,17 @@ def main():
             "value": cpu_mpix, "unit": "Mpix/s", "cores": 1, "kind": "port",
             "sample": f"{m} of the {F} frames, embed {t_embed:.2f} s + extract {t_extract:.2f} s, vectorised "
                       f"scipy.fftpack restatement (oracle/qim_dct_oracle.py), 1 thread"}
+        # the other direction: the GPU (fast mode) reading the ORACLE's stego frames must give the oracle's bits
+        ref_dev = torch.from_numpy(ref_stego).to(dev)
+        planes_m = Planes.contiguous(m, H, W)
+        batch.extract_device(ref_dev.data_ptr(), planes_m, delta, n_ac, extracted.data_ptr(), extracted.numel(), stream,
+                             mode="fast")
+        torch.cuda.synchronize()
+        got_bits = np.unpackbits(extracted[: (m * per + 7) // 8].cpu().numpy(), count=m * per)
         result["parity_sample"] = {
             "frames": m,
+            "gpu_extract_of_reference_stego_bit_mismatches": int((got_bits != ref_bits).sum()),
+            "bits_compared": int(m * per),
             "oracle_extract_of_gpu_stego_equals_payload": bool(np.array_equal(
                 orc.batch_extract_bits(gpu_stego[:1], delta if delta != int(delta) else int(delta), n_ac), bits[:per])),
             "psnr_frame0_reference_db": psnr_ref, "psnr_frame0_delta_db": abs(psnr_ref - psnr0),
