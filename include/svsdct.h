@@ -54,8 +54,9 @@ extern "C" {
  *   0                  FAST transforms: an FMA-factored float32 DCT restricted to the coefficient rows the
  *                      payload touches.  Meets the operator's contract - extracted bits bit-exact, stego PSNR
  *                      within 0.01 dB of the reference - and runs on the HBM roofline.  Stego pixels can differ
- *                      from the reference's where it resolves an exact rounding tie by float32 noise, and a block
- *                      that receives no coefficient change is left untouched.
+ *                      from the reference's where it resolves a rounding tie of c/delta by float32 noise (so can
+ *                      bits extracted from frames that were never embedded), and a block that receives no
+ *                      coefficient change is left untouched.
  *   SVS_EXACT_POCKETFFT  every float32 operation of scipy.fftpack.dct/idct(norm='ortho') (pocketfft) is
  *                      replayed in order, on all 64 coefficients: stego pixels, tie decisions and the
  *                      reference's round-trip artefacts (config_and_setup.py:166-171 on untouched blocks) are

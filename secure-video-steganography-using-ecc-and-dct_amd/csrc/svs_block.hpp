@@ -240,9 +240,14 @@ SVS_HD uint32_t block_budget(uint64_t first, uint64_t n_bits, uint32_t n) {
 }
 
 // Embed `nb` (0..n) payload bits, taken MSB-first from hi:lo, into the block held in rx[]/ry[].
-template <int U, int QM>
-SVS_HD void embed_block(uint32_t (&rx)[8], uint32_t (&ry)[8], uint32_t n, uint32_t nb, uint32_t hi, uint32_t lo,
+// NFIX > 0 fixes the coefficient count at compile time (the two everyday settings, n = 3 of the benchmark and
+// n = 10 of the reference's GUI default, get their own instantiation): transform outputs nobody reads and inverse
+// inputs that are known zeros then disappear from the code.  NFIX = 0 reads n at run time.
+template <int U, int QM, int NFIX = 0>
+SVS_HD void embed_block(uint32_t (&rx)[8], uint32_t (&ry)[8], uint32_t n_rt, uint32_t nb, uint32_t hi, uint32_t lo,
                         const QimParams &qp) {
+    static_assert(NFIX == 0 || (U <= 2 && NFIX / 8 + 1 == U), "NFIX must lie in coefficient row U-1, U <= 2");
+    const uint32_t n = NFIX ? (uint32_t)NFIX : n_rt;
     float D[U][8];
     forward_rows<U>(rx, ry, D);
 
@@ -270,9 +275,14 @@ SVS_HD void embed_block(uint32_t (&rx)[8], uint32_t (&ry)[8], uint32_t n, uint32
     // U non-zero inputs; trunc(clip(pixel + change)) == clip(pixel + floor(change)) for an integer
     // pixel (:171).  For U == 1 the change is the same in all 8 rows of a column.
     float P[U][8];
-    idct8<8, true>(D[0], P[0]);
+    if constexpr (NFIX == 0) {
+        idct8<8, true>(D[0], P[0]);
 #pragma unroll
-    for (int u = 1; u < U; ++u) idct8<8, false>(D[u], P[u]);
+        for (int u = 1; u < U; ++u) idct8<8, false>(D[u], P[u]);
+    } else {
+        idct8<(NFIX + 1 < 8 ? NFIX + 1 : 8), true>(D[0], P[0]);        // row 0: entries 1..min(n, 7) can be non-zero
+        if constexpr (U == 2) idct8<NFIX - 7, false>(D[1], P[1]);      // row 1: entries 0..n-8
+    }
 
 #define SVS_OUTCOL(X, W, B)                                                          \
     {                                                                                \
@@ -289,9 +299,10 @@ SVS_HD void embed_block(uint32_t (&rx)[8], uint32_t (&ry)[8], uint32_t n, uint32
 }
 
 // Parity bits of round(c_k/delta), k = 1..n, MSB-first into hi:lo (config_and_setup.py:160-161)
-template <int U, int QM>
-SVS_HD void extract_block(const uint32_t (&rx)[8], const uint32_t (&ry)[8], uint32_t n, const QimParams &qp,
+template <int U, int QM, int NFIX = 0>
+SVS_HD void extract_block(const uint32_t (&rx)[8], const uint32_t (&ry)[8], uint32_t n_rt, const QimParams &qp,
                           uint32_t &hi, uint32_t &lo) {
+    const uint32_t n = NFIX ? (uint32_t)NFIX : n_rt;
     float D[U][8];
     forward_rows<U>(rx, ry, D);
     hi = 0;

@@ -164,6 +164,17 @@ template <int QM, int BPL>
 int launch_extract(int rows, uint64_t total, hipStream_t st, const uint8_t *gray, const svs::Geometry &g,
                    const svs::QimParams &qp, uint8_t *out, uint64_t out_bytes) {
     const dim3 grid((uint32_t)((total + SVS_WG * BPL - 1) / (SVS_WG * BPL)));
+    // n = 10 (the reference GUI's default) has a compile-time-n instantiation of the extract kernel: +1..7 %
+    // (profiles/r01_ab_quant_exact.txt).  The same specialisation of the embed kernel measured SLOWER (-13 % at
+    // 600 x 4K, n = 10) and n = 3 gains nothing (HBM-bound), so those stay on the run-time-n kernels.
+    const bool fixed_n = env_chunk("SVS_FIXED_N", 1) != 0;   // experiment knob
+    if constexpr (BPL == 1) {
+        if (fixed_n && g.n_ac == 10) {
+            hipLaunchKernelGGL((svs::extract_kernel<2, QM, 1, 10>), grid, dim3(SVS_WG), 0, st, gray, g, qp, out, out_bytes);
+            SVS_HIP(hipGetLastError());
+            return SVS_OK;
+        }
+    }
 #define SVS_CASE(R)                                                                                                  \
     case R:                                                                                                          \
         hipLaunchKernelGGL((svs::extract_kernel<R, QM, BPL>), grid, dim3(SVS_WG), 0, st, gray, g, qp, out, out_bytes); \

@@ -107,7 +107,7 @@ __device__ __forceinline__ void store_rows(uint8_t *dst, int64_t row_pitch, cons
 // BPL = 2 needs an even number of blocks per row and 16-byte aligned rows (host checks).
 // HBM traffic per block: 64 B read + 64 B written + n payload bits read.
 // ---------------------------------------------------------------------------------------
-template <int U, int QM, int BPL>
+template <int U, int QM, int BPL, int NFIX = 0>
 __global__ __launch_bounds__(SVS_WG) void embed_kernel(const uint8_t *__restrict__ gray,
                                                     uint8_t *__restrict__ stego, const Geometry g,
                                                     const QimParams qp,
@@ -134,7 +134,7 @@ __global__ __launch_bounds__(SVS_WG) void embed_kernel(const uint8_t *__restrict
     {
         uint32_t hi, lo;
         payload_window(bits, n_words, bit_offset + first, hi, lo);
-        embed_block<U, QM>(ax, ay, n, block_budget(first, n_bits, n), hi, lo, qp);
+        embed_block<U, QM, NFIX>(ax, ay, n, block_budget(first, n_bits, n), hi, lo, qp);
     }
 #pragma unroll
     for (int r = 0; r < 8; ++r) { v[r].x = ax[r]; v[r].y = ay[r]; }
@@ -146,7 +146,7 @@ __global__ __launch_bounds__(SVS_WG) void embed_kernel(const uint8_t *__restrict
         // change, i.e. block B is stored back unchanged - no branch needed
         uint32_t hi, lo;
         payload_window(bits, n_words, bit_offset + first + n, hi, lo);
-        embed_block<U, QM>(bx, by, n, block_budget(first + n, n_bits, n), hi, lo, qp);
+        embed_block<U, QM, NFIX>(bx, by, n, block_budget(first + n, n_bits, n), hi, lo, qp);
 #pragma unroll
         for (int r = 0; r < 8; ++r) { v[r].z = bx[r]; v[r].w = by[r]; }
     }
@@ -198,7 +198,7 @@ __device__ __forceinline__ void emit_wave_bits(uint8_t *mine, uint32_t lane, uin
 // a wave-private LDS byte array and written with plain dword stores - no atomics, no pre-zeroed
 // output.  HBM traffic per block: 64 B read + n bits written.
 // ---------------------------------------------------------------------------------------
-template <int U, int QM, int BPL>
+template <int U, int QM, int BPL, int NFIX = 0>
 __global__ __launch_bounds__(SVS_WG) void extract_kernel(const uint8_t *__restrict__ gray, const Geometry g,
                                                       const QimParams qp, uint8_t *__restrict__ out,
                                                       const uint64_t out_bytes) {
@@ -216,12 +216,12 @@ __global__ __launch_bounds__(SVS_WG) void extract_kernel(const uint8_t *__restri
         uint32_t ax[8], ay[8];
 #pragma unroll
         for (int r = 0; r < 8; ++r) { ax[r] = v[r].x; ay[r] = v[r].y; }
-        extract_block<U, QM>(ax, ay, n, qp, hi_a, lo_a);
+        extract_block<U, QM, NFIX>(ax, ay, n, qp, hi_a, lo_a);
         if constexpr (BPL == 2) {
             uint32_t bx[8], by[8];
 #pragma unroll
             for (int r = 0; r < 8; ++r) { bx[r] = v[r].z; by[r] = v[r].w; }
-            extract_block<U, QM>(bx, by, n, qp, hi_b, lo_b);
+            extract_block<U, QM, NFIX>(bx, by, n, qp, hi_b, lo_b);
         }
     }
 

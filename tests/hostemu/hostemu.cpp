@@ -46,6 +46,13 @@ void embed_u(Blk &raw, uint32_t n, uint32_t nb, uint32_t hi, uint32_t lo, const 
     else svs::embed_block<U, svs::QM_F32>(raw.x, raw.y, n, nb, hi, lo, qp);
 }
 
+template <int U, int NFIX>
+void embed_fixed(Blk &raw, uint32_t nb, uint32_t hi, uint32_t lo, const svs::QimParams &qp, int qm) {
+    if (qm == svs::QM_DOUBLE) svs::embed_block<U, svs::QM_DOUBLE, NFIX>(raw.x, raw.y, NFIX, nb, hi, lo, qp);
+    else if (qm == svs::QM_POW2) svs::embed_block<U, svs::QM_POW2, NFIX>(raw.x, raw.y, NFIX, nb, hi, lo, qp);
+    else svs::embed_block<U, svs::QM_F32, NFIX>(raw.x, raw.y, NFIX, nb, hi, lo, qp);
+}
+
 void embed_dispatch(int rows, Blk &raw, uint32_t n, uint32_t nb, uint32_t hi, uint32_t lo,
                     const svs::QimParams &qp, int dbl) {
     switch (rows) {
@@ -62,6 +69,7 @@ void embed_dispatch(int rows, Blk &raw, uint32_t n, uint32_t nb, uint32_t hi, ui
 
 template <int QM>
 void extract_dispatch(int rows, const Blk &raw, uint32_t n, const svs::QimParams &d, uint32_t &hi, uint32_t &lo) {
+    if (n == 10) return svs::extract_block<2, QM, 10>(raw.x, raw.y, n, d, hi, lo);   // as csrc/svs_capi.hip
     switch (rows) {
         case 1: svs::extract_block<1, QM>(raw.x, raw.y, n, d, hi, lo); break;
         case 2: svs::extract_block<2, QM>(raw.x, raw.y, n, d, hi, lo); break;

@@ -4,11 +4,17 @@ import numpy as np
 from hypothesis import HealthCheck, given, settings
 from hypothesis import strategies as st
 
-from testlib import emu_embed, emu_extract, exact_tie_mask
+from testlib import emu_embed, emu_extract, near_tie_mask
 from oracle import qim_dct_oracle as orc
 
 DELTAS = st.sampled_from([1, 2, 3, 4, 5, 7.5, 8, 12, 16, 20, 33, 0.75, 100])
-COMMON = dict(deadline=None, max_examples=120, suppress_health_check=[HealthCheck.too_slow, HealthCheck.data_too_large])
+import os
+
+# derandomize: the suite the driver runs must not depend on the day's random seed; SVS_HYPOTHESIS_EXAMPLES raises the
+# example count (and re-randomises) for exploratory runs
+_EXPLORE = int(os.environ.get("SVS_HYPOTHESIS_EXAMPLES", "0"))
+COMMON = dict(deadline=None, max_examples=_EXPLORE or 200, derandomize=not _EXPLORE, database=None,
+              suppress_health_check=[HealthCheck.too_slow, HealthCheck.data_too_large])
 
 
 @st.composite
@@ -55,7 +61,7 @@ def test_exact_mode_equals_oracle_bit_for_bit(case):
 
 @settings(**COMMON)
 @given(cases())
-def test_fast_mode_bits_equal_oracle_outside_exact_ties(case):
+def test_fast_mode_bits_equal_oracle_away_from_rounding_ties(case):
     frames, delta, n_ac, bits, off = case
     stego, used = emu_embed(frames, delta, n_ac, bits, bit_offset=off, exact=False)
     n = max(0, min(n_ac, 63))
@@ -64,10 +70,6 @@ def test_fast_mode_bits_equal_oracle_outside_exact_ties(case):
     for src in (stego, frames):
         got = emu_extract(src, delta, n_ac, exact=False)
         want = orc.batch_extract_bits(src, delta, n_ac)
-        if delta == int(delta):
-            ties = np.concatenate([exact_tie_mask(fr, delta, n_ac).reshape(-1) for fr in src])
-        else:
-            ties = np.zeros(want.size, bool)
-            k = np.arange(want.size) % max(n, 1) + 1
-            ties = np.isin(k, [4, 32, 36])             # non-integer delta: skip the three tie-prone coefficients
+        ties = np.concatenate([near_tie_mask(fr, delta, n_ac).reshape(-1) for fr in src])
+        assert ties.size < 200 or ties.mean() < 0.2
         assert np.array_equal(got[~ties], want[~ties])

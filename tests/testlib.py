@@ -71,6 +71,23 @@ def exact_tie_mask(gray, delta, n_ac):
     return mask
 
 
+def near_tie_mask(gray, delta, n_ac, tol=1e-3):
+    """Boolean [blocks, n] mask of coefficients whose float64 value lies within `tol` of a rounding tie
+    (k + 1/2) * delta.  FAST mode computes the coefficients with a different (equally accurate) float32
+    factorisation than pocketfft, so on frames that were never embedded the two can land on different sides of
+    a tie when the true value is within float32 rounding error (~1e-5) of it; `tol` is 100x that.  Includes the
+    exact ties of exact_tie_mask().  EXACT mode needs no mask."""
+    from scipy.fftpack import dct
+    n = max(0, min(int(n_ac), 63))
+    h, w = gray.shape
+    blocks = gray.reshape(h // 8, 8, w // 8, 8).transpose(0, 2, 1, 3).reshape(-1, 8, 8).astype(np.float64)
+    if delta <= 0 or n == 0:
+        return np.zeros((blocks.shape[0], n), bool)
+    c = dct(dct(blocks, axis=1, norm="ortho"), axis=2, norm="ortho").reshape(-1, 64)[:, 1:1 + n]
+    t = c / float(delta)
+    return np.abs(np.abs(t - np.rint(t)) - 0.5) * float(delta) < tol
+
+
 # ---- test-only CPU emulation of the per-block kernel arithmetic (tests/hostemu) ---------------
 _EMU = None
 
