@@ -148,7 +148,7 @@ uint64_t emu_extract(const uint8_t *gray, int F, int H, int W, double delta, int
         Blk raw;
         raw.load(p, (size_t)W);
         uint32_t hi, lo;
-        if (exact) {
+        if (exact || svs::rows_for(n) == 1) {   // one coefficient row: both modes use the pocketfft-identical forward
             if (qm == svs::QM_POW2) svs::extract_block_exact<8, svs::QM_POW2>(raw.x, raw.y, (uint32_t)n, qp, hi, lo);
             else svs::extract_block_exact<8, svs::QM_F32>(raw.x, raw.y, (uint32_t)n, qp, hi, lo);
         } else if (qm == svs::QM_POW2) extract_dispatch<svs::QM_POW2>(svs::rows_for(n), raw, (uint32_t)n, qp, hi, lo);
