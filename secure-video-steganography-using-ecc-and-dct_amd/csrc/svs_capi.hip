@@ -441,10 +441,10 @@ int svs_extract_dev(const uint8_t *d_gray, const svs_planes *planes, double delt
         const int rows = rows_for(n);
         int rc;
         if (flags & ~SVS_EXACT_POCKETFFT) return fail(SVS_ERR_INVALID_ARG, "unknown flags 0x%x", flags);
-        // With one coefficient row (n <= 7) the pocketfft-identical forward transform costs nothing (the kernel is
-        // HBM-bound either way: 7.0-7.1 TB/s for both, profiles/r01_ab_quant_exact.txt), so FAST mode uses it too and
-        // extraction is bit-identical to the reference for ANY input frame.  With more rows it costs ~17 % and stays
-        // opt-in.
+        // With one coefficient row (n <= 7) the pocketfft-identical forward transform costs 0.2-3 % (the kernel stays
+        // HBM-bound; in-process A/B in profiles/r01_ab_quant_exact.txt), so FAST mode uses it too and extraction is
+        // bit-identical to the reference for ANY input frame.  With more rows it costs ~17 % and stays opt-in.
+        // SVS_FAST_EXTRACT_U1=1 (experiment knob) selects the FMA-factored forward instead.
         if ((flags & SVS_EXACT_POCKETFFT) || (rows == 1 && env_chunk("SVS_FAST_EXTRACT_U1", 0) == 0)) {
             rc = qm == svs::QM_POW2 ? launch_extract_exact<svs::QM_POW2>(rows, total, st, d_gray, g, qp, d_bits_packed_out, bytes)
                                     : launch_extract_exact<svs::QM_F32>(rows, total, st, d_gray, g, qp, d_bits_packed_out, bytes);

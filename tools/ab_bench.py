@@ -17,6 +17,7 @@ ap.add_argument("--frames", type=int, default=600); ap.add_argument("--rounds", 
 ap.add_argument("--n-ac", type=int, default=3); ap.add_argument("--delta", type=float, default=8.0)
 ap.add_argument("--h", type=int, default=2160); ap.add_argument("--w", type=int, default=3840)
 ap.add_argument("--mode", default="fast", choices=["fast", "exact"])
+ap.add_argument("--extract-u1-ab", action="store_true", help="A/B SVS_FAST_EXTRACT_U1=0 vs 1 on the first lib")
 ap.add_argument("--fixed-n-ab", action="store_true", help="A/B SVS_FIXED_N=1 vs 0 on the first lib")
 ap.add_argument("--chunks", default="", help="comma list: sweep SVS_*_XCD_CHUNK on the first lib")
 ap.add_argument("libs", nargs="+")
@@ -32,6 +33,8 @@ def load(path):
 libs = [(os.path.basename(p).replace("libsvsdct", "").replace(".so", "") or "base", load(p), None) for p in a.libs]
 if a.chunks:
     libs = [(f"chunk{c}", libs[0][1], c) for c in a.chunks.split(",")]
+if a.extract_u1_ab:
+    libs = [("exact_fwd", libs[0][1], "X0"), ("fast_fwd", libs[0][1], "X1")]
 if a.fixed_n_ab:
     libs = [("fixed_n", libs[0][1], "F1"), ("runtime_n", libs[0][1], "F0")]
 dev = torch.device("cuda", 0); torch.cuda.set_device(0)
@@ -50,7 +53,9 @@ digests = {}
 done = C.c_uint64()
 for r in range(a.rounds + 2):
     for name, lib, chunk in libs:
-        if chunk is not None and chunk.startswith("F"):
+        if chunk is not None and chunk.startswith("X"):
+            os.environ["SVS_FAST_EXTRACT_U1"] = chunk[1]
+        elif chunk is not None and chunk.startswith("F"):
             os.environ["SVS_FIXED_N"] = chunk[1]
         elif chunk is not None:
             os.environ["SVS_EMBED_XCD_CHUNK"] = chunk; os.environ["SVS_EXTRACT_XCD_CHUNK"] = chunk
