@@ -440,12 +440,12 @@ __global__ __launch_bounds__(256) void gray_to_bgr_kernel(const uint8_t *__restr
 // One workgroup = 256 output columns x SSIM_BAND output rows; a thread walks down its column keeping the
 // last 7 horizontal window sums of the five moments in registers.
 // ---------------------------------------------------------------------------------------
-#define SVS_SSIM_BAND 64
+#define SVS_SSIM_BAND 126  // output rows per workgroup (a multiple of 7 keeps the row groups aligned)
 __global__ __launch_bounds__(256) void ssim_partial_kernel(const uint8_t *__restrict__ a, const uint8_t *__restrict__ b,
                                                            int32_t height, int32_t width, int64_t row_pitch,
                                                            int64_t frame_pitch, const double *__restrict__ data_range,
                                                            double *__restrict__ partial) {
-    __shared__ uint8_t ra[256 + 6], rb[256 + 6];
+    __shared__ uint8_t ra[7][256 + 8], rb[7][256 + 8];  // 7 input rows at a time
     __shared__ double red[4];
     const int out_w = width - 6, out_h = height - 6;
     const int x0 = blockIdx.x * 256, y0 = blockIdx.y * SVS_SSIM_BAND, f = blockIdx.z;
@@ -454,41 +454,43 @@ __global__ __launch_bounds__(256) void ssim_partial_kernel(const uint8_t *__rest
     const double R = data_range[f];
     const double C1 = (0.01 * R) * (0.01 * R), C2 = (0.03 * R) * (0.03 * R);
     const double inv_np = 1.0 / 49.0, cov_norm = 49.0 / 48.0;
-    uint32_t ha[7], hb[7], haa[7], hbb[7], hab[7];  // ring of horizontal 7-sums, one entry per input row
+    // ring of the last 7 horizontal 7-sums of the five moments; slot = input row % 7, so with rows handled in groups
+    // of 7 every slot index below is a compile-time constant
+    uint32_t ha[7], hb[7], haa[7], hbb[7], hab[7];
     uint32_t va = 0, vb = 0, vaa = 0, vbb = 0, vab = 0;
 #pragma unroll
     for (int i = 0; i < 7; ++i) ha[i] = hb[i] = haa[i] = hbb[i] = hab[i] = 0;
     double acc = 0.0;
     const int rows = min(SVS_SSIM_BAND, out_h - y0) + 6;  // input rows this band touches
-    for (int r = 0; r < rows; ++r) {
-        const int y = y0 + r;
+    const bool col_ok = x0 + t < out_w;
+    for (int r0 = 0; r0 < rows; r0 += 7) {
         __syncthreads();
-        for (int i = t; i < 256 + 6; i += 256) {
-            const int x = x0 + i;
-            ra[i] = x < width ? pa[(int64_t)y * row_pitch + x] : 0;
-            rb[i] = x < width ? pb[(int64_t)y * row_pitch + x] : 0;
+        for (int i = t; i < 7 * (256 + 6); i += 256) {
+            const int j = i / (256 + 6), c = i - j * (256 + 6);
+            const int x = x0 + c, y = y0 + r0 + j;
+            const bool ok = x < width && y < height && r0 + j < rows;
+            ra[j][c] = ok ? pa[(int64_t)y * row_pitch + x] : 0;
+            rb[j][c] = ok ? pb[(int64_t)y * row_pitch + x] : 0;
         }
         __syncthreads();
-        uint32_t sa = 0, sb = 0, saa = 0, sbb = 0, sab = 0;
 #pragma unroll
-        for (int d = 0; d < 7; ++d) {
-            const uint32_t u = ra[t + d], v = rb[t + d];
-            sa += u; sb += v; saa += u * u; sbb += v * v; sab += u * v;
-        }
-        // slide the vertical window: slot r % 7 holds the row that leaves
+        for (int j = 0; j < 7; ++j) {
+            uint32_t sa = 0, sb = 0, saa = 0, sbb = 0, sab = 0;
 #pragma unroll
-        for (int k = 0; k < 7; ++k) {
-            if (k == r % 7) {
-                va += sa - ha[k]; vb += sb - hb[k]; vaa += saa - haa[k]; vbb += sbb - hbb[k]; vab += sab - hab[k];
-                ha[k] = sa; hb[k] = sb; haa[k] = saa; hbb[k] = sbb; hab[k] = sab;
+            for (int d = 0; d < 7; ++d) {
+                const uint32_t u = ra[j][t + d], v = rb[j][t + d];
+                sa += u; sb += v; saa += u * u; sbb += v * v; sab += u * v;
             }
-        }
-        if (r >= 6 && x0 + t < out_w) {
-            const double ux = va * inv_np, uy = vb * inv_np;
-            const double vx = cov_norm * (vaa * inv_np - ux * ux), vy = cov_norm * (vbb * inv_np - uy * uy);
-            const double vxy = cov_norm * (vab * inv_np - ux * uy);
-            const double A1 = 2.0 * ux * uy + C1, A2 = 2.0 * vxy + C2, B1 = ux * ux + uy * uy + C1, B2 = vx + vy + C2;
-            acc += (A1 * A2) / (B1 * B2);
+            va += sa - ha[j]; vb += sb - hb[j]; vaa += saa - haa[j]; vbb += sbb - hbb[j]; vab += sab - hab[j];
+            ha[j] = sa; hb[j] = sb; haa[j] = saa; hbb[j] = sbb; hab[j] = sab;
+            const int r = r0 + j;
+            if (r >= 6 && r < rows && col_ok) {
+                const double ux = va * inv_np, uy = vb * inv_np;
+                const double vx = cov_norm * (vaa * inv_np - ux * ux), vy = cov_norm * (vbb * inv_np - uy * uy);
+                const double vxy = cov_norm * (vab * inv_np - ux * uy);
+                const double A1 = 2.0 * ux * uy + C1, A2 = 2.0 * vxy + C2, B1 = ux * ux + uy * uy + C1, B2 = vx + vy + C2;
+                acc += (A1 * A2) / (B1 * B2);
+            }
         }
     }
 #pragma unroll
