@@ -484,6 +484,9 @@ __global__ __launch_bounds__(256) void ssim_partial_kernel(const uint8_t *__rest
             va += sa - ha[j]; vb += sb - hb[j]; vaa += saa - haa[j]; vbb += sbb - hbb[j]; vab += sab - hab[j];
             ha[j] = sa; hb[j] = sb; haa[j] = saa; hbb[j] = sbb; hab[j] = sab;
             const int r = r0 + j;
+#if defined(SVS_SSIM_DIAG_NO_F64)
+            if (r >= 6 && r < rows && col_ok) acc += (double)(va + vb + vaa + vbb + vab);
+#else
             if (r >= 6 && r < rows && col_ok) {
                 const double ux = va * inv_np, uy = vb * inv_np;
                 const double vx = cov_norm * (vaa * inv_np - ux * ux), vy = cov_norm * (vbb * inv_np - uy * uy);
@@ -491,6 +494,7 @@ __global__ __launch_bounds__(256) void ssim_partial_kernel(const uint8_t *__rest
                 const double A1 = 2.0 * ux * uy + C1, A2 = 2.0 * vxy + C2, B1 = ux * ux + uy * uy + C1, B2 = vx + vy + C2;
                 acc += (A1 * A2) / (B1 * B2);
             }
+#endif
         }
     }
 #pragma unroll
