@@ -445,7 +445,7 @@ __global__ __launch_bounds__(256) void ssim_partial_kernel(const uint8_t *__rest
                                                            int32_t height, int32_t width, int64_t row_pitch,
                                                            int64_t frame_pitch, const double *__restrict__ data_range,
                                                            double *__restrict__ partial) {
-    __shared__ uint8_t ra[7][256 + 8], rb[7][256 + 8];  // 7 input rows at a time
+    __shared__ __attribute__((aligned(8))) uint8_t ra[7][256 + 8], rb[7][256 + 8];  // 7 input rows at a time
     __shared__ double red[4];
     const int out_w = width - 6, out_h = height - 6;
     const int x0 = blockIdx.x * 256, y0 = blockIdx.y * SVS_SSIM_BAND, f = blockIdx.z;
@@ -465,12 +465,18 @@ __global__ __launch_bounds__(256) void ssim_partial_kernel(const uint8_t *__rest
     const bool col_ok = x0 + t < out_w;
     for (int r0 = 0; r0 < rows; r0 += 7) {
         __syncthreads();
-        for (int i = t; i < 7 * (256 + 6); i += 256) {
-            const int j = i / (256 + 6), c = i - j * (256 + 6);
-            const int x = x0 + c, y = y0 + r0 + j;
-            const bool ok = x < width && y < height && r0 + j < rows;
-            ra[j][c] = ok ? pa[(int64_t)y * row_pitch + x] : 0;
-            rb[j][c] = ok ? pb[(int64_t)y * row_pitch + x] : 0;
+        // stage 7 rows x 264 columns of both frames with 8-byte loads (x0 and the row pitch are multiples of 8, the
+        // width is a multiple of 8, so a chunk is either wholly inside the frame or wholly outside)
+        for (int i = t; i < 7 * 33; i += 256) {
+            const int j = i / 33, c8 = i - j * 33;
+            const int x = x0 + 8 * c8, y = y0 + r0 + j;
+            u32x2 qa = {0u, 0u}, qb = {0u, 0u};
+            if (x < width && y < height && r0 + j < rows) {
+                qa = *reinterpret_cast<const u32x2 *>(pa + (int64_t)y * row_pitch + x);
+                qb = *reinterpret_cast<const u32x2 *>(pb + (int64_t)y * row_pitch + x);
+            }
+            *reinterpret_cast<u32x2 *>(&ra[j][8 * c8]) = qa;
+            *reinterpret_cast<u32x2 *>(&rb[j][8 * c8]) = qb;
         }
         __syncthreads();
 #pragma unroll
@@ -479,7 +485,8 @@ __global__ __launch_bounds__(256) void ssim_partial_kernel(const uint8_t *__rest
 #pragma unroll
             for (int d = 0; d < 7; ++d) {
                 const uint32_t u = ra[j][t + d], v = rb[j][t + d];
-                sa += u; sb += v; saa += u * u; sbb += v * v; sab += u * v;
+                sa += u; sb += v;
+                saa += __umul24(u, u); sbb += __umul24(v, v); sab += __umul24(u, v);  // full-rate 24-bit multiplies
             }
             va += sa - ha[j]; vb += sb - hb[j]; vaa += saa - haa[j]; vbb += sbb - hbb[j]; vab += sab - hab[j];
             ha[j] = sa; hb[j] = sb; haa[j] = saa; hbb[j] = sbb; hab[j] = sab;
