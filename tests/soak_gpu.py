@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """One-off soak: many random geometries / parameters through the real kernels, fast mode vs the CPU build of the
-kernel header, exact mode vs the oracle (bit for bit).  usage: python tools/gpu_soak.py [iterations] [seed]"""
+kernel header, exact mode vs the oracle (bit for bit).  usage: python tests/soak_gpu.py [iterations] [seed]"""
 import os, sys
-REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))  # tests/ -> repo root
 for p in (os.path.join(REPO, "secure-video-steganography-using-ecc-and-dct_amd"), REPO, os.path.join(REPO, "tests")):
     sys.path.insert(0, p)
 import numpy as np
