@@ -59,6 +59,20 @@ def test_product_package_never_imports_the_oracle():
                     "tests/hostemu", ""), os.path.join(root, f)
 
 
+def test_only_tests_smoke_and_bench_touch_the_oracle():
+    """oracle/ is test infrastructure: besides tests/, only __graft_entry__.smoke() and bench.py's baseline /
+    checker legs may import it."""
+    allowed = {os.path.join(REPO, "bench.py"), os.path.join(REPO, "__graft_entry__.py")}
+    for root, dirs, files in os.walk(REPO):
+        dirs[:] = [d for d in dirs if d not in (".git", "tests", "oracle", "gpurun_out", "__pycache__", ".hypothesis",
+                                                ".pytest_cache")]
+        for f in files:
+            path = os.path.join(root, f)
+            if f.endswith(".py") and path not in allowed:
+                text = open(path).read()
+                assert "from oracle" not in text and "import oracle" not in text, path
+
+
 def test_bit_string_forms():
     import config_and_setup as cs
     assert cs.bytes_ke_bitstream(b"\x80\x01\xff") == "100000000000000111111111"
