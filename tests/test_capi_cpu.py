@@ -27,6 +27,17 @@ def test_library_exports_every_declared_symbol():
     assert lib.svs_abi_version() == native.ABI_VERSION == 2
 
 
+def test_header_is_plain_c_and_library_links_from_c(tmp_path):
+    import subprocess
+    exe = str(tmp_path / "use_header")
+    libdir = os.path.dirname(native.LIB_PATH)
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-I" + os.path.join(REPO, "include"),
+                           os.path.join(REPO, "tests", "capi_c", "use_header.c"), "-o", exe, "-L" + libdir, "-lsvsdct",
+                           "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0 and "c abi ok" in out.stdout, (out.returncode, out.stdout, out.stderr)
+
+
 def test_capacity_arithmetic_without_gpu():
     lib = native.load()
     p = native.Planes.contiguous(600, 2160, 3840)
