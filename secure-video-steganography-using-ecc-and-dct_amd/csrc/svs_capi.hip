@@ -672,6 +672,9 @@ int svs_ref_copy_dev(const void *d_src, void *d_dst, uint64_t bytes, int mode, v
     const auto *s = reinterpret_cast<const svs::u32x4 *>(d_src);
     auto *d = reinterpret_cast<svs::u32x4 *>(d_dst);
     if (mode == 0) hipLaunchKernelGGL(svs::copy_kernel<0>, dim3((uint32_t)((n16 + 255) / 256)), dim3(256), 0, st, s, d, n16);
+    else if (mode == 3) hipLaunchKernelGGL(svs::copy_kernel<3>, dim3((uint32_t)((n16 + 255) / 256)), dim3(256), 0, st, s, d, n16);
+    else if (mode == 4) hipLaunchKernelGGL(svs::copy_kernel<4>, dim3((uint32_t)((n16 + 255) / 256)), dim3(256), 0, st, s, d, n16);
+    else if (mode == 5) hipLaunchKernelGGL(svs::copy_kernel<5>, dim3((uint32_t)((n16 + 255) / 256)), dim3(256), 0, st, s, d, n16);
     else if (mode == 1) hipLaunchKernelGGL(svs::copy_kernel<1>, dim3(256 * 8), dim3(256), 0, st, s, d, n16);
     else hipLaunchKernelGGL(svs::copy_kernel<2>, dim3(256 * 8), dim3(256), 0, st, s, d, n16);
     SVS_HIP(hipGetLastError());

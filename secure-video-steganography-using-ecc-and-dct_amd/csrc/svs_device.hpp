@@ -98,8 +98,21 @@ __device__ __forceinline__ void load_rows(const uint8_t *src, int64_t row_pitch,
 
 template <int BPL>
 __device__ __forceinline__ void store_rows(uint8_t *dst, int64_t row_pitch, const typename RowVec<BPL>::type (&v)[8]) {
+#if !defined(SVS_NO_STORE_SC1)
+    // write-through (sc1) stores: the line is not kept in the XCD's L2 (measured against non-temporal stores,
+    // profiles/r01_ab_quant_exact.txt: one-shot copy 6.74 vs 6.55 TB/s; embed +1.5 % at n = 3, +9.5 % at n = 10).  The data registers must not be reused before
+    // the store has read them: s_nop 1 inside the string (cdna_hip_programming.md section 5.7 item 1).
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        if constexpr (BPL == 1)
+            asm volatile("global_store_dwordx2 %0, %1, off sc1\n\ts_nop 1" ::"v"(dst + r * row_pitch), "v"(v[r]) : "memory");
+        else
+            asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(dst + r * row_pitch), "v"(v[r]) : "memory");
+    }
+#else
 #pragma unroll
     for (int r = 0; r < 8; ++r) SVS_ST(v[r], reinterpret_cast<typename RowVec<BPL>::type *>(dst + r * row_pitch));
+#endif
 }
 
 // ---------------------------------------------------------------------------------------
@@ -554,7 +567,18 @@ __global__ __launch_bounds__(256) void frame_range_kernel(const uint8_t *__restr
 // thread, non-temporal;  mode 2: as 1 with default cache policy
 template <int MODE>
 __global__ __launch_bounds__(256) void copy_kernel(const u32x4 *__restrict__ src, u32x4 *__restrict__ dst, uint64_t n16) {
-    if constexpr (MODE == 0) {
+    if constexpr (MODE >= 3) {
+        // cache-policy experiments on the one-shot copy: 3 = nt load + sc1 (write-through) store, 4 = nt load + sc0 sc1 nt
+        // store, 5 = sc1 load + sc1 store
+        const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+        if (i < n16) {
+            u32x4 v;
+            if constexpr (MODE == 5) asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(src + i) : "memory");
+            else v = __builtin_nontemporal_load(src + i);
+            if constexpr (MODE == 4) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt" ::"v"(dst + i), "v"(v) : "memory");
+            else asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst + i), "v"(v) : "memory");
+        }
+    } else if constexpr (MODE == 0) {
         const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
         if (i < n16) __builtin_nontemporal_store(__builtin_nontemporal_load(src + i), dst + i);
     } else {

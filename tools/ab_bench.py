@@ -77,7 +77,8 @@ for r in range(a.rounds + 2):
             digests[name] += " roundtrip_ok" if same else " ROUNDTRIP_MISMATCH"
 # ceilings on this box: (1) the embed kernel's own access pattern with the arithmetic skipped (n_bits = 0 ->
 # every lane copies its block), (2) torch's contiguous device-to-device copy
-ceil = {"pattern_copy": [], "torch_copy": [], "copy16_nt": [], "copy_gridstride_nt": [], "copy_gridstride": [], "read_nt": []}
+ceil = {"pattern_copy": [], "torch_copy": [], "copy16_nt": [], "copy_gridstride_nt": [], "copy_gridstride": [], "read_nt": [],
+        "copy16_nt_sc1st": [], "copy16_nt_sc0sc1nt_st": [], "copy16_sc1ld_sc1st": []}
 l0.svs_ref_copy_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p]
 l0.svs_ref_read_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
 sink = torch.zeros(4096, dtype=torch.int32, device=dev)
@@ -88,6 +89,11 @@ for r in range(a.rounds + 2):
     e[1].record()
     stego.copy_(gray)
     e[2].record()
+    ey = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    ey[0].record()
+    for m in range(3):
+        assert l0.svs_ref_copy_dev(gray.data_ptr(), stego.data_ptr(), gray.numel(), 3 + m, st) == 0
+        ey[m + 1].record()
     ex = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
     ex[0].record()
     for m in range(3):
@@ -100,6 +106,8 @@ for r in range(a.rounds + 2):
         ceil["pattern_copy"].append(e[0].elapsed_time(e[1])); ceil["torch_copy"].append(e[1].elapsed_time(e[2]))
         for m, k in enumerate(["copy16_nt", "copy_gridstride_nt", "copy_gridstride"]):
             ceil[k].append(ex[m].elapsed_time(ex[m + 1]))
+        for m, k in enumerate(["copy16_nt_sc1st", "copy16_nt_sc0sc1nt_st", "copy16_sc1ld_sc1st"]):
+            ceil[k].append(ey[m].elapsed_time(ey[m + 1]))
         ceil["read_nt"].append(2 * ex[3].elapsed_time(ex[4]))   # x2: reported below against 2 B/px like the copies
 eb, xb = F * H * W * 2 + nbytes, F * H * W + nbytes
 for k, v in ceil.items():
