@@ -28,7 +28,11 @@ write_scale = px / (mean[("fill_synthetic_kernel", "WRITE_SIZE")] * 1024)
 out = {"workload": {"frames": F, "height": H, "width": W, "n_ac": n},
        "calibration": {"FETCH_SIZE_scale_from_frame_sse_kernel": fetch_scale,
                        "WRITE_SIZE_scale_from_fill_synthetic_kernel": write_scale}, "kernels": {}}
-for kern, alg in (("embed_kernel", 2 * px + px * n // 512), ("extract_kernel", px + px * n // 512)):
+extract_name = "extract_kernel" if ("extract_kernel", "FETCH_SIZE") in mean else "extract_exact_kernel"   # n <= 7 uses the exact one
+kerns = [("embed_kernel", 2 * px + px * n // 512), (extract_name, px + px * n // 512)]
+if ("embed_exact_kernel", "FETCH_SIZE") in mean:
+    kerns.append(("embed_exact_kernel", 2 * px + px * n // 512))
+for kern, alg in kerns:
     rd = mean[(kern, "FETCH_SIZE")] * 1024 * 2.0
     wr = mean[(kern, "WRITE_SIZE")] * 1024
     out["kernels"][kern] = {
@@ -44,7 +48,7 @@ with open(os.path.join(repo, "profiles", f"{tag}_pmc_summary.json"), "w") as fh:
 with open(os.path.join(repo, "profiles", "hbm_traffic.json"), "w") as fh:
     json.dump({"frames": F, "height": H, "width": W, "n_ac": n,
                "embed_bytes_per_launch": out["kernels"]["embed_kernel"]["hbm_bytes_per_launch"],
-               "extract_bytes_per_launch": out["kernels"]["extract_kernel"]["hbm_bytes_per_launch"],
+               "extract_bytes_per_launch": out["kernels"][extract_name]["hbm_bytes_per_launch"],
                "source": f"profiles/{tag}_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, tools/gpu_pmc.sh)"},
               fh, indent=1)
 print(json.dumps({k: {kk: vv for kk, vv in v.items() if kk != "raw_means"} for k, v in out["kernels"].items()}, indent=1))
