@@ -155,6 +155,27 @@ int svs_bgr_to_gray_dev(const uint8_t *d_bgr, int64_t bgr_row_pitch, int64_t bgr
 int svs_gray_to_bgr_dev(const uint8_t *d_gray, const svs_planes *planes, uint8_t *d_bgr, int64_t bgr_row_pitch,
                         int64_t bgr_frame_pitch, void *stream);
 
+/* Fused colour path: BGR frames in, stego BGR frames out, one pass (3 B/pixel read + 3 B/pixel written; the frame
+ * loop's cvtColor -> operator -> cvtColor at embed_process.py:117-127 for the frames that carry payload).
+ *   d_bgr_in / d_bgr_out : interleaved 8-bit BGR [frame][row][col][3]; pitches in bytes (multiples of 8; base
+ *                          pointers 8-byte aligned); may alias when the pitches are equal.
+ *   d_gray_ref           : optional (NULL to skip) gray planes, geometry `planes`: the gray frame BEFORE embedding,
+ *                          i.e. the operator's first return value (config_and_setup.py:112,172).
+ *   planes               : n_frames / height / width of the clip and the pitches of d_gray_ref.
+ *   weights, flags, bits : as svs_bgr_to_gray_dev / svs_embed_dev.  Every block of these frames is written (gray
+ *                          replicated into B, G, R); pass only the frames that carry payload - the reference copies
+ *                          the remaining frames in colour (embed_process.py:134-139). */
+int svs_embed_bgr_dev(const uint8_t *d_bgr_in, int64_t in_row_pitch, int64_t in_frame_pitch,
+                      uint8_t *d_bgr_out, int64_t out_row_pitch, int64_t out_frame_pitch,
+                      uint8_t *d_gray_ref, const svs_planes *planes, const uint32_t *weights,
+                      double delta, int n_ac, const uint8_t *d_bits_packed, uint64_t bit_offset, uint64_t n_bits,
+                      uint32_t flags, uint64_t *n_embedded, void *stream);
+/* Extract straight from interleaved BGR frames (gray computed on the fly, pocketfft-identical forward transform:
+ * the bits equal svs_extract_dev(..., SVS_EXACT_POCKETFFT) of svs_bgr_to_gray_dev's output). */
+int svs_extract_bgr_dev(const uint8_t *d_bgr, int64_t bgr_row_pitch, int64_t bgr_frame_pitch,
+                        const svs_planes *planes, const uint32_t *weights, double delta, int n_ac,
+                        uint8_t *d_bits_packed_out, uint64_t out_capacity_bytes, uint64_t *n_bits_out, void *stream);
+
 /* ---- measurement helpers (synthetic inputs and on-device checks for bench.py / tests) ------ */
 /* value = lo + hash32(seed, first_frame + f, y, x) % span  - same hash as svsdct/synth.py */
 int svs_fill_synthetic_dev(uint8_t *d_frames, const svs_planes *planes, uint32_t seed,

@@ -236,6 +236,30 @@ struct DevBuf {  // RAII for the host-pointer entry points
     }
 };
 
+template <int QM, bool EXACT>
+int launch_embed_bgr(int rows, uint64_t total, hipStream_t st, const uint8_t *in, uint8_t *out, uint8_t *ref,
+                            const svs::Geometry &g, const svs::ColourParams &c, const svs::QimParams &qp,
+                            const uint32_t *bits, uint64_t bit_offset, uint64_t n_bits, uint32_t n_words) {
+    const dim3 grid((uint32_t)((total + SVS_WG - 1) / SVS_WG));
+    if constexpr (EXACT) {
+        hipLaunchKernelGGL((svs::embed_bgr_kernel<8, QM, true>), grid, dim3(SVS_WG), 0, st, in, out, ref, g, c, qp, bits,
+                           bit_offset, n_bits, n_words);
+    } else {
+#define SVS_CASE(R)                                                                                                   \
+    case R:                                                                                                           \
+        hipLaunchKernelGGL((svs::embed_bgr_kernel<R, QM, false>), grid, dim3(SVS_WG), 0, st, in, out, ref, g, c, qp, bits, \
+                           bit_offset, n_bits, n_words);                                                              \
+        break;
+        switch (rows) {
+            SVS_CASE(1) SVS_CASE(2) SVS_CASE(3) SVS_CASE(4) SVS_CASE(5) SVS_CASE(6) SVS_CASE(7) SVS_CASE(8)
+            default: return fail(SVS_ERR_INVALID_ARG, "internal: rows=%d", rows);
+        }
+#undef SVS_CASE
+    }
+    SVS_HIP(hipGetLastError());
+    return SVS_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -568,6 +592,127 @@ int svs_gray_to_bgr_dev(const uint8_t *d_gray, const svs_planes *planes, uint8_t
                        planes->n_frames, planes->height, planes->width, planes->row_pitch, planes->frame_pitch,
                        bgr_row_pitch, bgr_frame_pitch);
     SVS_HIP(hipGetLastError());
+    return SVS_OK;
+}
+
+static int colour_params(const svs_planes *p, const void *in, int64_t irp, int64_t ifp, const void *out, int64_t orp,
+                         int64_t ofp, const uint32_t *weights, svs::ColourParams *c) {
+    const void *ptrs[2] = {in, out};
+    const int64_t rps[2] = {irp, orp}, fps[2] = {ifp, ofp};
+    for (int i = 0; i < 2; ++i) {
+        if (i == 1 && !out) break;
+        if (!ptrs[i] || ((uintptr_t)ptrs[i] % 8)) return fail(SVS_ERR_INVALID_ARG, "BGR pointer NULL or not 8-byte aligned");
+        if (rps[i] < 3 * (int64_t)p->width || (rps[i] % 8) || fps[i] < rps[i] * p->height || (fps[i] % 8))
+            return fail(SVS_ERR_INVALID_ARG, "BGR pitches must cover 3*width bytes per row and be multiples of 8");
+    }
+    const uint32_t dflt[4] = {3735u, 19235u, 9798u, 15u};
+    const uint32_t *w = weights ? weights : dflt;
+    if (w[3] < 1 || w[3] > 16 || w[0] + w[1] + w[2] != (1u << w[3]))
+        return fail(SVS_ERR_INVALID_ARG, "weights must sum to 2^shift with 1 <= shift <= 16");
+    c->in_row_pitch = irp; c->in_frame_pitch = ifp; c->out_row_pitch = orp; c->out_frame_pitch = ofp;
+    c->wb = w[0]; c->wg = w[1]; c->wr = w[2]; c->shift = w[3];
+    return SVS_OK;
+}
+
+int svs_embed_bgr_dev(const uint8_t *d_bgr_in, int64_t in_row_pitch, int64_t in_frame_pitch, uint8_t *d_bgr_out,
+                      int64_t out_row_pitch, int64_t out_frame_pitch, uint8_t *d_gray_ref, const svs_planes *planes,
+                      const uint32_t *weights, double delta, int n_ac, const uint8_t *d_bits_packed, uint64_t bit_offset,
+                      uint64_t n_bits, uint32_t flags, uint64_t *n_embedded, void *stream) {
+    svs::Geometry g;
+    uint64_t total = 0;
+    if (int rc = make_geometry(planes, n_ac, &g, &total)) return rc;
+    if (n_embedded) *n_embedded = 0;
+    if (total == 0) return SVS_OK;
+    if (flags & ~SVS_EXACT_POCKETFFT) return fail(SVS_ERR_INVALID_ARG, "unknown flags 0x%x", flags);
+    if (d_gray_ref && ((uintptr_t)d_gray_ref % 8)) return fail(SVS_ERR_INVALID_ARG, "gray pointer must be 8-byte aligned");
+    svs::ColourParams c;
+    if (int rc = colour_params(planes, d_bgr_in, in_row_pitch, in_frame_pitch, d_bgr_out, out_row_pitch, out_frame_pitch,
+                               weights, &c))
+        return rc;
+    if (!d_bgr_out) return fail(SVS_ERR_INVALID_ARG, "output pointer is NULL");
+    const int n = (int)g.n_ac;
+    const uint64_t cap = total * (uint64_t)n;
+    uint64_t use = n_bits < cap ? n_bits : cap;
+    if (!(delta > 0.0) || n == 0) use = 0;
+    if (use > 0 && (!d_bits_packed || ((uintptr_t)d_bits_packed % 4)))
+        return fail(SVS_ERR_INVALID_ARG, "bits pointer NULL or not 4-byte aligned");
+    const bool exact = (flags & SVS_EXACT_POCKETFFT) != 0;
+    svs::QimParams qp;
+    const int qm = make_qim(use == 0 ? 1.0 : delta, &qp);
+    g.xcd_chunk = env_chunk("SVS_EMBED_XCD_CHUNK", kEighth);
+    const hipStream_t st = (hipStream_t)stream;
+    const uint32_t *bw = reinterpret_cast<const uint32_t *>(d_bits_packed);
+    uint64_t kernel_bits = use;
+    uint32_t words = 0;
+    if (use == 0) {
+        // nothing to embed.  EXACT with a non-empty payload: every block is still round-tripped (n_ac = 0 in the kernel);
+        // otherwise the frames are just converted BGR -> gray -> BGR
+        if (exact && n_bits > 0) { g.n_ac = 0; kernel_bits = 1; } else { g.n_ac = 1; kernel_bits = 0; }
+        bw = nullptr;
+    } else {
+        const uint64_t w64 = ((bit_offset + use + 7) / 8 + 3) / 4;
+        if (w64 >= (1ull << 32)) return fail(SVS_ERR_INVALID_ARG, "payload too large for one call");
+        words = (uint32_t)w64;
+    }
+    const int rows = rows_for((int)g.n_ac);
+    int rc;
+#define SVS_GO(QM)                                                                                                       \
+    rc = exact ? launch_embed_bgr<QM, true>(rows, total, st, d_bgr_in, d_bgr_out, d_gray_ref, g, c, qp, bw, bit_offset,   \
+                                            kernel_bits, words)                                                           \
+               : launch_embed_bgr<QM, false>(rows, total, st, d_bgr_in, d_bgr_out, d_gray_ref, g, c, qp, bw, bit_offset,  \
+                                             kernel_bits, words)
+    if (qm == svs::QM_DOUBLE) SVS_GO(svs::QM_DOUBLE);
+    else if (qm == svs::QM_POW2) SVS_GO(svs::QM_POW2);
+    else SVS_GO(svs::QM_F32);
+#undef SVS_GO
+    if (rc) return rc;
+    if (n_embedded) *n_embedded = use;
+    return SVS_OK;
+}
+
+int svs_extract_bgr_dev(const uint8_t *d_bgr, int64_t bgr_row_pitch, int64_t bgr_frame_pitch, const svs_planes *planes,
+                        const uint32_t *weights, double delta, int n_ac, uint8_t *d_bits_packed_out,
+                        uint64_t out_capacity_bytes, uint64_t *n_bits_out, void *stream) {
+    svs::Geometry g;
+    uint64_t total = 0;
+    if (int rc = make_geometry(planes, n_ac, &g, &total)) return rc;
+    if (n_bits_out) *n_bits_out = 0;
+    const int n = (int)g.n_ac;
+    const uint64_t cap = total * (uint64_t)n;
+    if (cap == 0) return SVS_OK;
+    svs::ColourParams c;
+    if (int rc = colour_params(planes, d_bgr, bgr_row_pitch, bgr_frame_pitch, nullptr, 0, 0, weights, &c)) return rc;
+    if (!d_bits_packed_out || ((uintptr_t)d_bits_packed_out % 4)) return fail(SVS_ERR_INVALID_ARG, "bits pointer NULL or unaligned");
+    const uint64_t bytes = (cap + 7) / 8;
+    if (out_capacity_bytes < bytes)
+        return fail(SVS_ERR_CAPACITY, "extract needs %llu bytes, buffer has %llu", (unsigned long long)bytes,
+                    (unsigned long long)out_capacity_bytes);
+    const hipStream_t st = (hipStream_t)stream;
+    if (!(delta > 0.0)) {
+        SVS_HIP(hipMemsetAsync(d_bits_packed_out, 0, bytes, st));
+    } else {
+        svs::QimParams qp;
+        const int qm = make_qim(delta, &qp);
+        g.xcd_chunk = env_chunk("SVS_EXTRACT_XCD_CHUNK", rows_for(n) == 1 ? 32u : kEighth);
+        const dim3 grid((uint32_t)((total + SVS_WG - 1) / SVS_WG));
+        const int rows = rows_for(n);
+#define SVS_CASE(R)                                                                                                      \
+    case R:                                                                                                              \
+        if (qm == svs::QM_POW2)                                                                                          \
+            hipLaunchKernelGGL((svs::extract_bgr_kernel<R, svs::QM_POW2>), grid, dim3(SVS_WG), 0, st, d_bgr, g, c, qp,   \
+                               d_bits_packed_out, bytes);                                                                \
+        else                                                                                                             \
+            hipLaunchKernelGGL((svs::extract_bgr_kernel<R, svs::QM_F32>), grid, dim3(SVS_WG), 0, st, d_bgr, g, c, qp,    \
+                               d_bits_packed_out, bytes);                                                                \
+        break;
+        switch (rows) {
+            SVS_CASE(1) SVS_CASE(2) SVS_CASE(3) SVS_CASE(4) SVS_CASE(5) SVS_CASE(6) SVS_CASE(7) SVS_CASE(8)
+            default: return fail(SVS_ERR_INVALID_ARG, "internal: rows=%d", rows);
+        }
+#undef SVS_CASE
+        SVS_HIP(hipGetLastError());
+    }
+    if (n_bits_out) *n_bits_out = cap;
     return SVS_OK;
 }
 

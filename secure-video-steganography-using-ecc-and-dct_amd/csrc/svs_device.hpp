@@ -448,6 +448,125 @@ __global__ __launch_bounds__(256) void gray_to_bgr_kernel(const uint8_t *__restr
 }
 
 // ---------------------------------------------------------------------------------------
+// Fused colour path ("fused read of 3 B/px"): the frames that carry payload go
+// BGR -> gray -> embed -> BGR in ONE pass - 3 B/pixel read, 3 B/pixel written (+1 for the optional gray
+// reference the operator returns) instead of the 10 B/pixel of convert / embed / convert.  One lane = one
+// block = 8 rows x 24 bytes; stego pixels are written as B = G = R = gray (cv2.COLOR_GRAY2BGR).  Every block
+// of these frames is converted; blocks past the payload budget carry their gray value unchanged.
+// ---------------------------------------------------------------------------------------
+struct ColourParams {
+    int64_t in_row_pitch, in_frame_pitch;    // BGR input
+    int64_t out_row_pitch, out_frame_pitch;  // BGR output
+    uint32_t wb, wg, wr, shift;              // (B*wb + G*wg + R*wr + 2^(shift-1)) >> shift
+};
+
+__device__ __forceinline__ int64_t block_offset_bgr(uint32_t gblock, const Geometry &g, int64_t row_pitch,
+                                                    int64_t frame_pitch) {
+    const uint32_t frame = fast_div(gblock, g.by_bpf);
+    const uint32_t in_frame = gblock - frame * g.by_bpf.div;
+    const uint32_t brow = fast_div(in_frame, g.by_wb);
+    const uint32_t bcol = in_frame - brow * g.by_wb.div;
+    return (int64_t)frame * frame_pitch + (int64_t)(brow * 8u) * row_pitch + (int64_t)(bcol * 24u);
+}
+
+// 8 interleaved BGR pixels (6 dwords) -> 8 gray bytes (2 dwords)
+__device__ __forceinline__ void bgr8_to_gray(const u32x2 &q0, const u32x2 &q1, const u32x2 &q2, const ColourParams &c,
+                                             uint32_t &lo4, uint32_t &hi4) {
+    const uint32_t w[6] = {q0.x, q0.y, q1.x, q1.y, q2.x, q2.y};
+    const uint32_t half = 1u << (c.shift - 1);
+    uint32_t px[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int b0 = 3 * j, b1 = 3 * j + 1, b2 = 3 * j + 2;
+        const uint32_t B = (w[b0 >> 2] >> (8 * (b0 & 3))) & 0xffu, G = (w[b1 >> 2] >> (8 * (b1 & 3))) & 0xffu,
+                       R = (w[b2 >> 2] >> (8 * (b2 & 3))) & 0xffu;
+        px[j] = (B * c.wb + G * c.wg + R * c.wr + half) >> c.shift;
+    }
+    lo4 = px[0] | (px[1] << 8) | (px[2] << 16) | (px[3] << 24);
+    hi4 = px[4] | (px[5] << 8) | (px[6] << 16) | (px[7] << 24);
+}
+
+// 8 gray bytes -> 8 interleaved BGR pixels with B = G = R
+__device__ __forceinline__ void gray8_to_bgr(uint32_t lo4, uint32_t hi4, u32x2 &q0, u32x2 &q1, u32x2 &q2) {
+    const uint32_t a = lo4 & 0xff, b = (lo4 >> 8) & 0xff, c = (lo4 >> 16) & 0xff, d = lo4 >> 24;
+    const uint32_t e = hi4 & 0xff, f = (hi4 >> 8) & 0xff, g = (hi4 >> 16) & 0xff, h = hi4 >> 24;
+    q0.x = a * 0x010101u | (b << 24);
+    q0.y = b * 0x0101u | (c * 0x0101u << 16);
+    q1.x = c | (d * 0x010101u << 8);
+    q1.y = e * 0x010101u | (f << 24);
+    q2.x = f * 0x0101u | (g * 0x0101u << 16);
+    q2.y = g | (h * 0x010101u << 8);
+}
+
+template <int U, int QM, bool EXACT>
+__global__ __launch_bounds__(SVS_WG) void embed_bgr_kernel(const uint8_t *__restrict__ bgr_in,
+                                                        uint8_t *__restrict__ bgr_out, uint8_t *__restrict__ gray_ref,
+                                                        const Geometry g, const ColourParams c, const QimParams qp,
+                                                        const uint32_t *__restrict__ bits, const uint64_t bit_offset,
+                                                        const uint64_t n_bits, const uint32_t n_words) {
+    const uint32_t gblock = tile_id(g.xcd_chunk) * (uint32_t)SVS_WG + threadIdx.x;
+    if (gblock >= g.total_blocks) return;
+    const uint8_t *src = bgr_in + block_offset_bgr(gblock, g, c.in_row_pitch, c.in_frame_pitch);
+    uint32_t ax[8], ay[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const u32x2 *row = reinterpret_cast<const u32x2 *>(src + r * c.in_row_pitch);
+        const u32x2 q0 = SVS_LD(row), q1 = SVS_LD(row + 1), q2 = SVS_LD(row + 2);
+        bgr8_to_gray(q0, q1, q2, c, ax[r], ay[r]);
+    }
+    if (gray_ref != nullptr) {  // the operator's first return value: the gray frame before embedding
+        uint8_t *ref = gray_ref + block_offset(gblock, g);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            u32x2 v; v.x = ax[r]; v.y = ay[r];
+            SVS_ST(v, reinterpret_cast<u32x2 *>(ref + r * g.row_pitch));
+        }
+    }
+    const uint32_t n = g.n_ac;
+    const uint64_t first = (uint64_t)gblock * n;
+    if (first < n_bits) {
+        uint32_t hi, lo;
+        payload_window(bits, n_words, bit_offset + first, hi, lo);
+        if constexpr (EXACT) embed_block_exact<8, QM>(ax, ay, n, block_budget(first, n_bits, n), hi, lo, qp);
+        else embed_block<U, QM>(ax, ay, n, block_budget(first, n_bits, n), hi, lo, qp);
+    }
+    uint8_t *dst = bgr_out + block_offset_bgr(gblock, g, c.out_row_pitch, c.out_frame_pitch);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        u32x2 q0, q1, q2;
+        gray8_to_bgr(ax[r], ay[r], q0, q1, q2);
+        u32x2 *row = reinterpret_cast<u32x2 *>(dst + r * c.out_row_pitch);
+        SVS_ST(q0, row); SVS_ST(q1, row + 1); SVS_ST(q2, row + 2);
+    }
+}
+
+// extract straight from interleaved BGR frames (gray computed on the fly; pocketfft-identical forward)
+template <int U, int QM>
+__global__ __launch_bounds__(SVS_WG) void extract_bgr_kernel(const uint8_t *__restrict__ bgr, const Geometry g,
+                                                          const ColourParams c, const QimParams qp,
+                                                          uint8_t *__restrict__ out, const uint64_t out_bytes) {
+    __shared__ __attribute__((aligned(16))) uint8_t flags[SVS_WG / 64][64 * 64];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t tile = tile_id(g.xcd_chunk);
+    const uint32_t gblock = tile * (uint32_t)SVS_WG + threadIdx.x;
+    const uint32_t n = g.n_ac;
+    uint32_t hi = 0, lo = 0;
+    if (gblock < g.total_blocks) {
+        const uint8_t *src = bgr + block_offset_bgr(gblock, g, c.in_row_pitch, c.in_frame_pitch);
+        uint32_t ax[8], ay[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const u32x2 *row = reinterpret_cast<const u32x2 *>(src + r * c.in_row_pitch);
+            const u32x2 q0 = SVS_LD(row), q1 = SVS_LD(row + 1), q2 = SVS_LD(row + 2);
+            bgr8_to_gray(q0, q1, q2, c, ax[r], ay[r]);
+        }
+        extract_block_exact<U, QM>(ax, ay, n, qp, hi, lo);
+    }
+    emit_wave_bits<U, 1>(&flags[wave][0], lane, (uint64_t)tile * (uint32_t)SVS_WG + wave * 64u, n, hi, lo, 0u, 0u, out,
+                         out_bytes);
+}
+
+// ---------------------------------------------------------------------------------------
 // SSIM evaluator: mean structural similarity of two gray frames as
 // skimage.metrics.structural_similarity computes it with its defaults for 2-D uint8 input (what the
 // reference's evaluation.calc_ssim calls, evaluation.py:21-26): 7x7 uniform window, K1 = 0.01, K2 = 0.03,

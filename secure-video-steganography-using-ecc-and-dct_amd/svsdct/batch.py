@@ -157,6 +157,133 @@ def extract_device(d_gray: int, planes: Planes, delta, n_ac, d_bits_out: int, ou
     return int(got.value)
 
 
+# ---- fused colour path (BGR in, BGR out) ---------------------------------
+def _weights_arg(weights):
+    if weights is None:
+        return None, None
+    w = np.ascontiguousarray(weights, np.uint32)
+    if w.shape != (4,):
+        raise ValueError("weights must be (wb, wg, wr, shift)")
+    return w, w.ctypes.data
+
+
+def embed_bgr_device(d_bgr_in: int, d_bgr_out: int, d_gray_ref: int, planes: Planes, delta, n_ac,
+                     d_bits_packed: int, bit_offset: int, n_bits: int, stream: int = 0, mode: str | None = None,
+                     weights=None, in_pitches=None, out_pitches=None) -> int:
+    """Enqueue the fused BGR -> gray -> embed -> BGR kernel over packed (or pitched) interleaved BGR frames;
+    `d_gray_ref` (0 to skip) receives the gray frames before embedding.  Returns bits embedded."""
+    irp, ifp = in_pitches or (3 * planes.width, 3 * planes.width * planes.height)
+    orp, ofp = out_pitches or (3 * planes.width, 3 * planes.width * planes.height)
+    keep, wptr = _weights_arg(weights)
+    done = C.c_uint64(0)
+    rc = native.load().svs_embed_bgr_dev(d_bgr_in, irp, ifp, d_bgr_out, orp, ofp, d_gray_ref or None,
+                                         C.byref(planes), wptr, float(delta), int(n_ac), d_bits_packed,
+                                         int(bit_offset), int(n_bits), mode_flags(mode, "fast"), C.byref(done),
+                                         stream or None)
+    native.check(rc, "svs_embed_bgr_dev")
+    return int(done.value)
+
+
+def extract_bgr_device(d_bgr: int, planes: Planes, delta, n_ac, d_bits_out: int, out_capacity_bytes: int,
+                       stream: int = 0, weights=None, pitches=None) -> int:
+    """Enqueue extraction straight from interleaved BGR frames; returns the number of bits the batch yields."""
+    rp, fp = pitches or (3 * planes.width, 3 * planes.width * planes.height)
+    keep, wptr = _weights_arg(weights)
+    got = C.c_uint64(0)
+    rc = native.load().svs_extract_bgr_dev(d_bgr, rp, fp, C.byref(planes), wptr, float(delta), int(n_ac),
+                                           d_bits_out, int(out_capacity_bytes), C.byref(got), stream or None)
+    native.check(rc, "svs_extract_bgr_dev")
+    return int(got.value)
+
+
+class _Scratch:
+    """Device allocations of one host-level call, released together."""
+
+    def __init__(self):
+        self._ptrs = []
+
+    def alloc(self, nbytes: int) -> int:
+        p = C.c_void_p()
+        native.check(native.load().svs_malloc(C.byref(p), max(8, int(nbytes))), "svs_malloc")
+        self._ptrs.append(p.value)
+        return p.value
+
+    def release(self) -> None:
+        for p in self._ptrs:
+            native.load().svs_free(p)
+        self._ptrs = []
+
+
+def _as_bgr_stack(frames: np.ndarray) -> np.ndarray:
+    a = np.asarray(frames)
+    if a.dtype != np.uint8 or a.ndim != 4 or a.shape[3] != 3:
+        raise TypeError("frames must be uint8 [F,H,W,3] (BGR)")
+    if a.shape[1] % 8 or a.shape[2] % 8:
+        raise ValueError("frame height and width must be multiples of 8")
+    return np.ascontiguousarray(a)
+
+
+def embed_bgr_frames(frames_bgr: np.ndarray, delta, n_ac, bits, bit_offset: int = 0, n_bits: int | None = None,
+                     device: int = 0, mode: str | None = None, weights=None, want_gray: bool = True):
+    """BGR frames in, stego BGR frames out (one fused pass on the GPU).
+    Returns (stego_bgr uint8 [F,H,W,3], gray uint8 [F,H,W] or None, n_embedded)."""
+    lib = native.load()
+    native.ensure_device(device)
+    stack = _as_bgr_stack(frames_bgr)
+    f, h, w, _ = stack.shape
+    if isinstance(bits, str):
+        bits = str_to_bits(bits)
+    bits = np.asarray(bits, np.uint8)
+    if n_bits is None:
+        n_bits = max(0, bits.size - bit_offset)
+    if bit_offset + n_bits > bits.size:
+        raise ValueError("bit_offset + n_bits exceeds the payload length")
+    packed = pack_bits(bits)
+    planes = Planes.contiguous(f, h, w)
+    out = np.empty_like(stack)
+    gray = np.empty((f, h, w), np.uint8) if want_gray else None
+    mem = _Scratch()
+    try:
+        d_in = mem.alloc(stack.nbytes)
+        d_out = mem.alloc(stack.nbytes)
+        d_gray = mem.alloc(f * h * w) if want_gray else 0
+        d_bits = mem.alloc(packed.nbytes)
+        native.check(lib.svs_memcpy_h2d(d_in, stack.ctypes.data, stack.nbytes, None), "h2d")
+        native.check(lib.svs_memcpy_h2d(d_bits, packed.ctypes.data, packed.nbytes, None), "h2d")
+        used = embed_bgr_device(d_in, d_out, d_gray, planes, delta, n_ac, d_bits, bit_offset, n_bits,
+                                mode=mode or _ENV_MODE or "exact", weights=weights)
+        native.check(lib.svs_memcpy_d2h(out.ctypes.data, d_out, out.nbytes, None), "d2h")
+        if want_gray:
+            native.check(lib.svs_memcpy_d2h(gray.ctypes.data, d_gray, gray.nbytes, None), "d2h")
+        native.check(lib.svs_stream_synchronize(None), "sync")
+    finally:
+        mem.release()
+    return out, gray, used
+
+
+def extract_bgr_frames(frames_bgr: np.ndarray, delta, n_ac, device: int = 0, weights=None):
+    """Extract the packed bit stream straight from BGR frames.  Returns (packed uint8, n_bits)."""
+    lib = native.load()
+    native.ensure_device(device)
+    stack = _as_bgr_stack(frames_bgr)
+    f, h, w, _ = stack.shape
+    cap = capacity_bits(f, h, w, n_ac)
+    nbytes = max(4, (cap + 7) // 8 + (-((cap + 7) // 8)) % 4)
+    out = np.zeros(nbytes, np.uint8)
+    planes = Planes.contiguous(f, h, w)
+    mem = _Scratch()
+    try:
+        d_in = mem.alloc(stack.nbytes)
+        d_out = mem.alloc(nbytes)
+        native.check(lib.svs_memcpy_h2d(d_in, stack.ctypes.data, stack.nbytes, None), "h2d")
+        n = extract_bgr_device(d_in, planes, delta, n_ac, d_out, nbytes, weights=weights)
+        native.check(lib.svs_memcpy_d2h(out.ctypes.data, d_out, nbytes, None), "d2h")
+        native.check(lib.svs_stream_synchronize(None), "sync")
+    finally:
+        mem.release()
+    return out[: (n + 7) // 8], n
+
+
 # ---- frame sharding across ranks (SURVEY 8(e)) ----------------------------------------------
 def shard_frames(n_frames: int, world_size: int, rank: int) -> tuple[int, int]:
     """Contiguous frame range [first, first+count) of `rank`, so that the global bit stream is the

@@ -464,6 +464,63 @@ def test_device_colour_conversions():
         native.SVS_ERR_INVALID_ARG
 
 
+@pytest.mark.parametrize("mode", ["exact", "fast"])
+def test_fused_colour_embed_equals_convert_embed_convert(mode):
+    """SURVEY 8(f) rank 2 ("fused read of 3 B/px"): BGR in -> stego BGR out in one kernel must equal
+    cvtColor -> operator -> cvtColor (embed_process.py:117-127) done step by step: same gray reference, same stego
+    planes (replicated into B, G, R), same bit count; and extraction straight from BGR frames equals extraction
+    from their gray planes.  In exact mode the stego planes are also the oracle's, pixel for pixel."""
+    rng = np.random.default_rng(17)
+    for (f, h, w, n_ac, delta, short) in ((2, 24, 40, 3, 8, 0), (3, 64, 128, 10, 12.5, 37), (1, 8, 8, 63, 5, 0),
+                                          (2, 16, 24, 20, 0.3, 11), (1, 32, 32, 7, 16, 1000000)):
+        bgr = rng.integers(0, 256, (f, h, w, 3), dtype=np.uint8)
+        bgr[0, :8, :8] = 130                                            # flat block: DC only
+        gray = np.stack([d_gray_default(x) for x in bgr])
+        cap = batch.capacity_bits(f, h, w, n_ac)
+        payload = synth.synthetic_bits(max(1, cap - short), seed=f * 100 + n_ac)
+        want_stego, want_used = batch.embed_frames(gray, delta, n_ac, payload, mode=mode)
+        got_bgr, got_gray, used = batch.embed_bgr_frames(bgr, delta, n_ac, payload, mode=mode)
+        assert used == want_used
+        assert np.array_equal(got_gray, gray)
+        assert np.array_equal(got_bgr, np.repeat(want_stego[..., None], 3, axis=3)), (f, h, w, n_ac, delta)
+        if mode == "exact":
+            ref_stego, ref_used = orc.batch_embed(gray, delta, payload, n_ac)
+            assert ref_used == used and np.array_equal(got_bgr[..., 1], ref_stego)
+        for src in (got_bgr, bgr):                                      # stego frames and never-embedded frames
+            packed, n_bits = batch.extract_bgr_frames(src, delta, n_ac)
+            src_gray = np.stack([d_gray_default(x) for x in src])
+            assert n_bits == cap
+            assert np.array_equal(np.unpackbits(packed, count=n_bits), orc.batch_extract_bits(src_gray, delta, n_ac))
+    # custom weight table + no gray reference + empty payload (frames are just converted)
+    bgr = rng.integers(0, 256, (1, 40, 48, 3), dtype=np.uint8)
+    w14 = np.array([1868, 9617, 4899, 14], np.uint32)
+    b, g, r = (bgr[..., i].astype(np.uint32) for i in range(3))
+    g14 = ((b * 1868 + g * 9617 + r * 4899 + 8192) >> 14).astype(np.uint8)
+    out, none, used = batch.embed_bgr_frames(bgr, 8, 3, np.zeros(0, np.uint8), mode=mode, weights=w14, want_gray=False)
+    assert none is None and used == 0 and np.array_equal(out, np.repeat(g14[..., None], 3, axis=3))
+    want, _ = batch.embed_frames(g14, 8, 3, np.ones(50, np.uint8), mode=mode)
+    out, _, used = batch.embed_bgr_frames(bgr, 8, 3, np.ones(50, np.uint8), mode=mode, weights=w14)
+    assert used == 50 and np.array_equal(out[..., 0], want)
+
+
+def test_fused_colour_argument_checks():
+    lib = native.load()
+    planes = Planes.contiguous(1, 8, 8)
+    d = _Dev(1024)
+    bad_w = np.array([1, 2, 3, 15], np.uint32)
+    args = dict(delta=8.0, n_ac=3)
+    assert lib.svs_embed_bgr_dev(d.ptr, 24, 192, d.ptr, 24, 192, None, C.byref(planes), bad_w.ctypes.data, 8.0, 3,
+                                 d.ptr, 0, 8, 0, None, None) == native.SVS_ERR_INVALID_ARG
+    assert lib.svs_embed_bgr_dev(d.ptr, 20, 192, d.ptr, 24, 192, None, C.byref(planes), None, 8.0, 3,
+                                 d.ptr, 0, 8, 0, None, None) == native.SVS_ERR_INVALID_ARG       # pitch < 3*width
+    assert lib.svs_embed_bgr_dev(d.ptr, 24, 192, None, 24, 192, None, C.byref(planes), None, 8.0, 3,
+                                 d.ptr, 0, 8, 0, None, None) == native.SVS_ERR_INVALID_ARG       # no output
+    assert lib.svs_embed_bgr_dev(d.ptr, 24, 192, d.ptr, 24, 192, None, C.byref(planes), None, 8.0, 3,
+                                 d.ptr, 0, 8, 4, None, None) == native.SVS_ERR_INVALID_ARG       # unknown flag
+    assert lib.svs_extract_bgr_dev(d.ptr, 24, 192, C.byref(planes), None, 8.0, 3, d.ptr, 0, None, None) == \
+        native.SVS_ERR_CAPACITY
+
+
 def d_gray_default(frame_bgr):
     b, g, r = (frame_bgr[..., i].astype(np.uint32) for i in range(3))
     return ((b * 3735 + g * 19235 + r * 9798 + 16384) >> 15).astype(np.uint8)

@@ -31,3 +31,26 @@ timed("gray_to_bgr", lambda: native.check(lib.svs_gray_to_bgr_dev(gray.data_ptr(
 lib.svs_fill_synthetic_dev(gray2.data_ptr(), C.byref(planes), 1, 0, 16, 224, st)
 timed("frame_sse (PSNR)", lambda: native.check(lib.svs_frame_sse_dev(gray.data_ptr(), gray2.data_ptr(), C.byref(planes), sse.data_ptr(), st), "x"), 2 * px)
 timed("frame_ssim", lambda: native.check(lib.svs_frame_ssim_dev(gray.data_ptr(), gray2.data_ptr(), C.byref(planes), None, ssim.data_ptr(), work.data_ptr(), st), "x"), 2 * px)
+
+# fused colour path vs the three-step chain (convert, embed, convert) on the same frames
+from svsdct import batch
+n_ac, delta = 3, 8.0
+cap = batch.capacity_bits(F, H, W, n_ac)
+bits = torch.empty((cap + 7) // 8 + 8, dtype=torch.uint8, device=dev)
+lib.svs_fill_bits_dev(bits.data_ptr(), cap, 5, 0, st)
+out_bits = torch.empty_like(bits)
+for mode in ("fast", "exact"):
+    def chain():
+        native.check(lib.svs_bgr_to_gray_dev(bgr.data_ptr(), 3 * W, 3 * W * H, gray.data_ptr(), C.byref(planes), None, st), "x")
+        batch.embed_device(gray.data_ptr(), gray2.data_ptr(), planes, delta, n_ac, bits.data_ptr(), 0, cap, st, mode=mode)
+        native.check(lib.svs_gray_to_bgr_dev(gray2.data_ptr(), C.byref(planes), back.data_ptr(), 3 * W, 3 * W * H, st), "x")
+    timed(f"3-step chain {mode}", chain, 10 * px)
+    timed(f"fused embed_bgr {mode}", lambda: batch.embed_bgr_device(bgr.data_ptr(), back.data_ptr(), 0, planes, delta, n_ac, bits.data_ptr(), 0, cap, st, mode=mode), 6 * px)
+    timed(f"fused +gray ref {mode}", lambda: batch.embed_bgr_device(bgr.data_ptr(), back.data_ptr(), gray.data_ptr(), planes, delta, n_ac, bits.data_ptr(), 0, cap, st, mode=mode), 7 * px)
+def chain_x():
+    native.check(lib.svs_bgr_to_gray_dev(back.data_ptr(), 3 * W, 3 * W * H, gray.data_ptr(), C.byref(planes), None, st), "x")
+    batch.extract_device(gray.data_ptr(), planes, delta, n_ac, out_bits.data_ptr(), out_bits.numel(), st)
+timed("2-step extract chain", chain_x, 5 * px)
+timed("fused extract_bgr", lambda: batch.extract_bgr_device(back.data_ptr(), planes, delta, n_ac, out_bits.data_ptr(), out_bits.numel(), st), 3 * px)
+torch.cuda.synchronize()
+print("fused round trip bit errors:", int((out_bits[: cap // 8] != bits[: cap // 8]).sum().item()))
