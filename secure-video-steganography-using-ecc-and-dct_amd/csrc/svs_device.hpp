@@ -469,6 +469,17 @@ __device__ __forceinline__ int64_t block_offset_bgr(uint32_t gblock, const Geome
     return (int64_t)frame * frame_pitch + (int64_t)(brow * 8u) * row_pitch + (int64_t)(bcol * 24u);
 }
 
+// One block row of interleaved BGR = 24 bytes at an 8-byte aligned address: three 8-byte accesses.  (A 16-byte +
+// an 8-byte access is no faster for loads and 1.7x SLOWER for stores - the 16-byte half is misaligned half the time.)
+__device__ __forceinline__ void load_bgr_row(const uint8_t *p, u32x2 &q0, u32x2 &q1, u32x2 &q2) {
+    const u32x2 *row = reinterpret_cast<const u32x2 *>(p);
+    q0 = SVS_LD(row); q1 = SVS_LD(row + 1); q2 = SVS_LD(row + 2);
+}
+__device__ __forceinline__ void store_bgr_row(uint8_t *p, const u32x2 &q0, const u32x2 &q1, const u32x2 &q2) {
+    u32x2 *row = reinterpret_cast<u32x2 *>(p);
+    SVS_ST(q0, row); SVS_ST(q1, row + 1); SVS_ST(q2, row + 2);
+}
+
 // 8 interleaved BGR pixels (6 dwords) -> 8 gray bytes (2 dwords)
 __device__ __forceinline__ void bgr8_to_gray(const u32x2 &q0, const u32x2 &q1, const u32x2 &q2, const ColourParams &c,
                                              uint32_t &lo4, uint32_t &hi4) {
@@ -480,64 +491,109 @@ __device__ __forceinline__ void bgr8_to_gray(const u32x2 &q0, const u32x2 &q1, c
         const int b0 = 3 * j, b1 = 3 * j + 1, b2 = 3 * j + 2;
         const uint32_t B = (w[b0 >> 2] >> (8 * (b0 & 3))) & 0xffu, G = (w[b1 >> 2] >> (8 * (b1 & 3))) & 0xffu,
                        R = (w[b2 >> 2] >> (8 * (b2 & 3))) & 0xffu;
-        px[j] = (B * c.wb + G * c.wg + R * c.wr + half) >> c.shift;
+        // B, G, R < 2^8 and the weights <= 2^16: 24-bit multiplies (full rate) are exact
+        px[j] = (__umul24(B, c.wb) + __umul24(G, c.wg) + __umul24(R, c.wr) + half) >> c.shift;
     }
     lo4 = px[0] | (px[1] << 8) | (px[2] << 16) | (px[3] << 24);
     hi4 = px[4] | (px[5] << 8) | (px[6] << 16) | (px[7] << 24);
 }
 
-// 8 gray bytes -> 8 interleaved BGR pixels with B = G = R
+// 8 gray bytes -> 8 interleaved BGR pixels with B = G = R: six byte permutes (v_perm_b32 selects bytes 0-3 from
+// its second operand, 4-7 from its first)
 __device__ __forceinline__ void gray8_to_bgr(uint32_t lo4, uint32_t hi4, u32x2 &q0, u32x2 &q1, u32x2 &q2) {
-    const uint32_t a = lo4 & 0xff, b = (lo4 >> 8) & 0xff, c = (lo4 >> 16) & 0xff, d = lo4 >> 24;
-    const uint32_t e = hi4 & 0xff, f = (hi4 >> 8) & 0xff, g = (hi4 >> 16) & 0xff, h = hi4 >> 24;
-    q0.x = a * 0x010101u | (b << 24);
-    q0.y = b * 0x0101u | (c * 0x0101u << 16);
-    q1.x = c | (d * 0x010101u << 8);
-    q1.y = e * 0x010101u | (f << 24);
-    q2.x = f * 0x0101u | (g * 0x0101u << 16);
-    q2.y = g | (h * 0x010101u << 8);
+    q0.x = __builtin_amdgcn_perm(0u, lo4, 0x01000000u);  // a a a b
+    q0.y = __builtin_amdgcn_perm(0u, lo4, 0x02020101u);  // b b c c
+    q1.x = __builtin_amdgcn_perm(0u, lo4, 0x03030302u);  // c d d d
+    q1.y = __builtin_amdgcn_perm(0u, hi4, 0x01000000u);
+    q2.x = __builtin_amdgcn_perm(0u, hi4, 0x02020101u);
+    q2.y = __builtin_amdgcn_perm(0u, hi4, 0x03030302u);
 }
 
+// Stego rows leave through a wave-private LDS tile (SVS_BGR_DIRECT_STORE disables it): each lane parks its 8 stego gray
+// bytes per row, then the wave writes the BGR row as 192 consecutive 8-byte units - unit u = bytes [8*(u%3), +8) of the
+// 24-byte row of the wave's block u/3 - so every store instruction covers 512 contiguous bytes instead of 8 bytes in
+// every 24.
 template <int U, int QM, bool EXACT>
 __global__ __launch_bounds__(SVS_WG) void embed_bgr_kernel(const uint8_t *__restrict__ bgr_in,
                                                         uint8_t *__restrict__ bgr_out, uint8_t *__restrict__ gray_ref,
                                                         const Geometry g, const ColourParams c, const QimParams qp,
                                                         const uint32_t *__restrict__ bits, const uint64_t bit_offset,
                                                         const uint64_t n_bits, const uint32_t n_words) {
+#if !defined(SVS_BGR_DIRECT_STORE)
+    __shared__ __attribute__((aligned(16))) u32x2 tile[SVS_WG / 64][8][64];
+#endif
     const uint32_t gblock = tile_id(g.xcd_chunk) * (uint32_t)SVS_WG + threadIdx.x;
-    if (gblock >= g.total_blocks) return;
-    const uint8_t *src = bgr_in + block_offset_bgr(gblock, g, c.in_row_pitch, c.in_frame_pitch);
+    const bool live = gblock < g.total_blocks;
+#if defined(SVS_BGR_DIRECT_STORE)
+    if (!live) return;
+#endif
     uint32_t ax[8], ay[8];
-#pragma unroll
-    for (int r = 0; r < 8; ++r) {
-        const u32x2 *row = reinterpret_cast<const u32x2 *>(src + r * c.in_row_pitch);
-        const u32x2 q0 = SVS_LD(row), q1 = SVS_LD(row + 1), q2 = SVS_LD(row + 2);
-        bgr8_to_gray(q0, q1, q2, c, ax[r], ay[r]);
-    }
-    if (gray_ref != nullptr) {  // the operator's first return value: the gray frame before embedding
-        uint8_t *ref = gray_ref + block_offset(gblock, g);
+    if (live) {
+        const uint8_t *src = bgr_in + block_offset_bgr(gblock, g, c.in_row_pitch, c.in_frame_pitch);
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
-            u32x2 v; v.x = ax[r]; v.y = ay[r];
-            SVS_ST(v, reinterpret_cast<u32x2 *>(ref + r * g.row_pitch));
+            u32x2 q0, q1, q2;
+            load_bgr_row(src + r * c.in_row_pitch, q0, q1, q2);
+            bgr8_to_gray(q0, q1, q2, c, ax[r], ay[r]);
+        }
+        if (gray_ref != nullptr) {  // the operator's first return value: the gray frame before embedding
+            uint8_t *ref = gray_ref + block_offset(gblock, g);
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                u32x2 v; v.x = ax[r]; v.y = ay[r];
+                SVS_ST(v, reinterpret_cast<u32x2 *>(ref + r * g.row_pitch));
+            }
+        }
+        const uint32_t n = g.n_ac;
+        const uint64_t first = (uint64_t)gblock * n;
+        if (first < n_bits) {
+            uint32_t hi, lo;
+            payload_window(bits, n_words, bit_offset + first, hi, lo);
+            if constexpr (EXACT) embed_block_exact<8, QM>(ax, ay, n, block_budget(first, n_bits, n), hi, lo, qp);
+            else embed_block<U, QM>(ax, ay, n, block_budget(first, n_bits, n), hi, lo, qp);
         }
     }
-    const uint32_t n = g.n_ac;
-    const uint64_t first = (uint64_t)gblock * n;
-    if (first < n_bits) {
-        uint32_t hi, lo;
-        payload_window(bits, n_words, bit_offset + first, hi, lo);
-        if constexpr (EXACT) embed_block_exact<8, QM>(ax, ay, n, block_budget(first, n_bits, n), hi, lo, qp);
-        else embed_block<U, QM>(ax, ay, n, block_budget(first, n_bits, n), hi, lo, qp);
-    }
+#if defined(SVS_BGR_DIRECT_STORE)
     uint8_t *dst = bgr_out + block_offset_bgr(gblock, g, c.out_row_pitch, c.out_frame_pitch);
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
         u32x2 q0, q1, q2;
         gray8_to_bgr(ax[r], ay[r], q0, q1, q2);
-        u32x2 *row = reinterpret_cast<u32x2 *>(dst + r * c.out_row_pitch);
-        SVS_ST(q0, row); SVS_ST(q1, row + 1); SVS_ST(q2, row + 2);
+        store_bgr_row(dst + r * c.out_row_pitch, q0, q1, q2);
     }
+#else
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    if (live) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) { u32x2 v; v.x = ax[r]; v.y = ay[r]; tile[wave][r][lane] = v; }
+    }
+    // wave-private tile: LDS operations of one wave execute in order; the fences only pin the compiler's order
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const uint32_t wave_first = gblock - lane;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const uint32_t u = lane + 64u * j;
+        const uint32_t owner = (u * 171u) >> 9;  // u / 3 for u < 192
+        const uint32_t part = u - 3u * owner;
+        if (wave_first + owner >= g.total_blocks) continue;
+        // gray pixels feeding the unit's two dwords (v_perm_b32: selector bytes 0-3 pick from the low gray dword,
+        // 4-7 from the high one): part 0 = p0 p0 p0 p1 | p1 p1 p2 p2, part 1 = p2 p3 p3 p3 | p4 p4 p4 p5,
+        // part 2 = p5 p5 p6 p6 | p6 p7 p7 p7
+        const uint32_t sel0 = part == 0 ? 0x01000000u : part == 1 ? 0x03030302u : 0x06060505u;
+        const uint32_t sel1 = part == 0 ? 0x02020101u : part == 1 ? 0x05040404u : 0x07070706u;
+        uint8_t *dst = bgr_out + block_offset_bgr(wave_first + owner, g, c.out_row_pitch, c.out_frame_pitch) + 8u * part;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const u32x2 v = tile[wave][r][owner];
+            u32x2 q;
+            q.x = __builtin_amdgcn_perm(v.y, v.x, sel0);
+            q.y = __builtin_amdgcn_perm(v.y, v.x, sel1);
+            asm volatile("global_store_dwordx2 %0, %1, off sc1\n\ts_nop 1" ::"v"(dst + r * c.out_row_pitch), "v"(q) : "memory");
+        }
+    }
+#endif
 }
 
 // extract straight from interleaved BGR frames (gray computed on the fly; pocketfft-identical forward)
@@ -556,8 +612,8 @@ __global__ __launch_bounds__(SVS_WG) void extract_bgr_kernel(const uint8_t *__re
         uint32_t ax[8], ay[8];
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
-            const u32x2 *row = reinterpret_cast<const u32x2 *>(src + r * c.in_row_pitch);
-            const u32x2 q0 = SVS_LD(row), q1 = SVS_LD(row + 1), q2 = SVS_LD(row + 2);
+            u32x2 q0, q1, q2;
+            load_bgr_row(src + r * c.in_row_pitch, q0, q1, q2);
             bgr8_to_gray(q0, q1, q2, c, ax[r], ay[r]);
         }
         extract_block_exact<U, QM>(ax, ay, n, qp, hi, lo);

@@ -24,7 +24,7 @@ def timed(name, fn, nbytes, reps=10):
         fn(); ev[i + 1].record()
     torch.cuda.synchronize()
     ms = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(reps))[reps // 2]
-    print(f"{name:22s} {ms:8.3f} ms  {nbytes / ms / 1e6:8.1f} GB/s  ({F * H * W / ms / 1e6:.2f} Gpix/ms-scale: {F*H*W/ms/1e9*1e3:.0f} Gpix/s)")
+    print(f"{name:24s} {ms:8.3f} ms  {nbytes / ms / 1e6:8.1f} GB/s  {F * H * W / ms / 1e6:7.0f} Gpixel/s")
 px = F * H * W
 timed("bgr_to_gray", lambda: native.check(lib.svs_bgr_to_gray_dev(bgr.data_ptr(), 3 * W, 3 * W * H, gray.data_ptr(), C.byref(planes), None, st), "x"), 4 * px)
 timed("gray_to_bgr", lambda: native.check(lib.svs_gray_to_bgr_dev(gray.data_ptr(), C.byref(planes), back.data_ptr(), 3 * W, 3 * W * H, st), "x"), 4 * px)
