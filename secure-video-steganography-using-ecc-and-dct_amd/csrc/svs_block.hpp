@@ -352,43 +352,72 @@ namespace pf {
 // They remove 20 of 78 (DCT-II) and 8 of 66 (DCT-III) operations.  (Subnormal intermediates, which would
 // break the first identity, cannot occur for pixel-derived data: non-zero values stay above 2^-40.)
 
+// Every function below is written once for T = float (one line of 8 values) and T = f32x2 (two independent lines,
+// component k of every value belonging to line k).  On gfx950 the two-line form compiles to packed-FP32 instructions
+// (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32: two IEEE-754 single operations per issue slot), each component rounding
+// exactly like the scalar operation - so the results stay bit-identical while the instruction count halves.
+typedef float f32x2 __attribute__((vector_size(8)));
+
+template <class T> SVS_HD T splat(float v);
+template <> SVS_HD float splat<float>(float v) { return v; }
+template <> SVS_HD f32x2 splat<f32x2>(float v) { const f32x2 r = {v, v}; return r; }
+
+SVS_HD float fma_t(float a, float b, float c) { return fmaf(a, b, c); }
+SVS_HD f32x2 fma_t(f32x2 a, f32x2 b, f32x2 c) {
+#if defined(__has_builtin)
+#if __has_builtin(__builtin_elementwise_fma)
+#define SVS_HAVE_ELEMENTWISE_FMA 1
+#endif
+#endif
+#if defined(SVS_HAVE_ELEMENTWISE_FMA)
+    return __builtin_elementwise_fma(a, b, c);
+#else
+    const f32x2 r = {fmaf(a[0], b[0], c[0]), fmaf(a[1], b[1], c[1])};
+    return r;
+#endif
+}
+
 // backward real FFT (halfcomplex -> real) of length 8, UNSCALED (the caller folds fct)
-SVS_HD void rfft8_backward(const float (&c)[8], float (&o)[8]) {
+template <class T>
+SVS_HD void rfft8_backward(const T (&c)[8], T (&o)[8]) {
+    const T W = splat<T>(SVS_PF_W), two = splat<T>(2.0f), mtwo = splat<T>(-2.0f);
     // radb2, ido = 4, l1 = 1   (h3 = 2*c3 and h7 = -2*c4 are consumed as FMAs below)
-    const float h0 = c[0] + c[7], h4 = c[0] - c[7];
-    const float h1 = c[1] + c[5], tr2 = c[1] - c[5];
-    const float ti2 = c[2] + c[6], h2 = c[2] - c[6];
-    const float h6 = SVS_PF_W * ti2 + SVS_PF_W * tr2;
-    const float h5 = SVS_PF_W * tr2 - SVS_PF_W * ti2;
+    const T h0 = c[0] + c[7], h4 = c[0] - c[7];
+    const T h1 = c[1] + c[5], tr2 = c[1] - c[5];
+    const T ti2 = c[2] + c[6], h2 = c[2] - c[6];
+    const T h6 = W * ti2 + W * tr2;
+    const T h5 = W * tr2 - W * ti2;
     // radb4, ido = 1, l1 = 2:  a = h[4k] + h[4k+3], b = h[4k] - h[4k+3], out = a +- 2 h[4k+1], b +- 2 h[4k+2]
-    const float a0 = fmaf(2.0f, c[3], h0), b0 = fmaf(-2.0f, c[3], h0);
-    o[0] = fmaf(2.0f, h1, a0);
-    o[4] = fmaf(-2.0f, h1, a0);
-    o[6] = fmaf(2.0f, h2, b0);
-    o[2] = fmaf(-2.0f, h2, b0);
-    const float a1 = fmaf(-2.0f, c[4], h4), b1 = fmaf(2.0f, c[4], h4);
-    o[1] = fmaf(2.0f, h5, a1);
-    o[5] = fmaf(-2.0f, h5, a1);
-    o[7] = fmaf(2.0f, h6, b1);
-    o[3] = fmaf(-2.0f, h6, b1);
+    const T a0 = fma_t(two, c[3], h0), b0 = fma_t(mtwo, c[3], h0);
+    o[0] = fma_t(two, h1, a0);
+    o[4] = fma_t(mtwo, h1, a0);
+    o[6] = fma_t(two, h2, b0);
+    o[2] = fma_t(mtwo, h2, b0);
+    const T a1 = fma_t(mtwo, c[4], h4), b1 = fma_t(two, c[4], h4);
+    o[1] = fma_t(two, h5, a1);
+    o[5] = fma_t(mtwo, h5, a1);
+    o[7] = fma_t(two, h6, b1);
+    o[3] = fma_t(mtwo, h6, b1);
 }
 
 // forward real FFT (real -> halfcomplex) of length 8, UNSCALED (the caller folds fct)
-SVS_HD void rfft8_forward(const float (&c)[8], float (&o)[8]) {
-    float y[8];
+template <class T>
+SVS_HD void rfft8_forward(const T (&c)[8], T (&o)[8]) {
+    const T W = splat<T>(SVS_PF_W);
+    T y[8];
     // radf4, ido = 1, l1 = 2
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
-        const float tr1 = c[k + 6] + c[k + 2];
+        const T tr1 = c[k + 6] + c[k + 2];
         y[4 * k + 2] = c[k + 6] - c[k + 2];
-        const float tr2 = c[k] + c[k + 4];
+        const T tr2 = c[k] + c[k + 4];
         y[4 * k + 1] = c[k] - c[k + 4];
         y[4 * k] = tr2 + tr1;
         y[4 * k + 3] = tr2 - tr1;
     }
     // radf2, ido = 4, l1 = 1
-    const float tr2 = SVS_PF_W * y[5] + SVS_PF_W * y[6];
-    const float ti2 = SVS_PF_W * y[6] - SVS_PF_W * y[5];
+    const T tr2 = W * y[5] + W * y[6];
+    const T ti2 = W * y[6] - W * y[5];
     o[0] = y[0] + y[4];
     o[7] = y[0] - y[4];
     o[4] = -y[7];
@@ -400,61 +429,63 @@ SVS_HD void rfft8_forward(const float (&c)[8], float (&o)[8]) {
 }
 
 // scipy.fftpack.dct(x, type=2, norm='ortho') for 8 float32 values
-SVS_HD void dct2_8(const float (&x)[8], float (&X)[8]) {
-    float c[8];
-    c[0] = x[0] * 2.0f;
-    c[7] = x[7] * 2.0f;
+template <class T>
+SVS_HD void dct2_8(const T (&x)[8], T (&X)[8]) {
+    T c[8];
+    c[0] = x[0] * splat<T>(2.0f);
+    c[7] = x[7] * splat<T>(2.0f);
 #pragma unroll
     for (int k = 1; k < 7; k += 2) {  // MPINPLACE(c[k+1], c[k])
         c[k + 1] = x[k + 1] - x[k];
         c[k] = x[k] + x[k + 1];
     }
-    float r[8];
+    T r[8];
     rfft8_backward(c, r);
     // post-pass: pocketfft computes 0.5*(t1 +- t2) with t = T*(0.25 r) +- T*(0.25 r); here T/8 carries both scalings
     {
-        const float t1 = (SVS_PF_T0 * 0.125f) * r[7] + (SVS_PF_T6 * 0.125f) * r[1];
-        const float t2 = (SVS_PF_T0 * 0.125f) * r[1] - (SVS_PF_T6 * 0.125f) * r[7];
+        const T t1 = splat<T>(SVS_PF_T0 * 0.125f) * r[7] + splat<T>(SVS_PF_T6 * 0.125f) * r[1];
+        const T t2 = splat<T>(SVS_PF_T0 * 0.125f) * r[1] - splat<T>(SVS_PF_T6 * 0.125f) * r[7];
         X[1] = t1 + t2;
         X[7] = t1 - t2;
     }
     {
-        const float t1 = (SVS_PF_T1 * 0.125f) * r[6] + (SVS_PF_T5 * 0.125f) * r[2];
-        const float t2 = (SVS_PF_T1 * 0.125f) * r[2] - (SVS_PF_T5 * 0.125f) * r[6];
+        const T t1 = splat<T>(SVS_PF_T1 * 0.125f) * r[6] + splat<T>(SVS_PF_T5 * 0.125f) * r[2];
+        const T t2 = splat<T>(SVS_PF_T1 * 0.125f) * r[2] - splat<T>(SVS_PF_T5 * 0.125f) * r[6];
         X[2] = t1 + t2;
         X[6] = t1 - t2;
     }
     {
-        const float t1 = (SVS_PF_T2 * 0.125f) * r[5] + (SVS_PF_T4 * 0.125f) * r[3];
-        const float t2 = (SVS_PF_T2 * 0.125f) * r[3] - (SVS_PF_T4 * 0.125f) * r[5];
+        const T t1 = splat<T>(SVS_PF_T2 * 0.125f) * r[5] + splat<T>(SVS_PF_T4 * 0.125f) * r[3];
+        const T t2 = splat<T>(SVS_PF_T2 * 0.125f) * r[3] - splat<T>(SVS_PF_T4 * 0.125f) * r[5];
         X[3] = t1 + t2;
         X[5] = t1 - t2;
     }
-    X[4] = r[4] * (SVS_PF_T3 * 0.25f);
-    X[0] = r[0] * (SVS_PF_SQRT2 * 0.125f);
+    X[4] = r[4] * splat<T>(SVS_PF_T3 * 0.25f);
+    X[0] = r[0] * splat<T>(SVS_PF_SQRT2 * 0.125f);
 }
 
 // scipy.fftpack.idct(X, type=2, norm='ortho') (= DCT-III) for 8 float32 values
-SVS_HD void dct3_8(const float (&X)[8], float (&x)[8]) {
-    float c[8];  // pre-pass with the FFT's fct = 0.25 folded into the constants
-    c[0] = X[0] * (SVS_PF_SQRT2 * 0.25f);
+template <class T>
+SVS_HD void dct3_8(const T (&X)[8], T (&x)[8]) {
+    T c[8];  // pre-pass with the FFT's fct = 0.25 folded into the constants
+    c[0] = X[0] * splat<T>(SVS_PF_SQRT2 * 0.25f);
     {
-        const float t1 = X[1] + X[7], t2 = X[1] - X[7];
-        c[1] = (SVS_PF_T0 * 0.25f) * t2 + (SVS_PF_T6 * 0.25f) * t1;
-        c[7] = (SVS_PF_T0 * 0.25f) * t1 - (SVS_PF_T6 * 0.25f) * t2;
+        const T t1 = X[1] + X[7], t2 = X[1] - X[7];
+        c[1] = splat<T>(SVS_PF_T0 * 0.25f) * t2 + splat<T>(SVS_PF_T6 * 0.25f) * t1;
+        c[7] = splat<T>(SVS_PF_T0 * 0.25f) * t1 - splat<T>(SVS_PF_T6 * 0.25f) * t2;
     }
     {
-        const float t1 = X[2] + X[6], t2 = X[2] - X[6];
-        c[2] = (SVS_PF_T1 * 0.25f) * t2 + (SVS_PF_T5 * 0.25f) * t1;
-        c[6] = (SVS_PF_T1 * 0.25f) * t1 - (SVS_PF_T5 * 0.25f) * t2;
+        const T t1 = X[2] + X[6], t2 = X[2] - X[6];
+        c[2] = splat<T>(SVS_PF_T1 * 0.25f) * t2 + splat<T>(SVS_PF_T5 * 0.25f) * t1;
+        c[6] = splat<T>(SVS_PF_T1 * 0.25f) * t1 - splat<T>(SVS_PF_T5 * 0.25f) * t2;
     }
     {
-        const float t1 = X[3] + X[5], t2 = X[3] - X[5];
-        c[3] = (SVS_PF_T2 * 0.25f) * t2 + (SVS_PF_T4 * 0.25f) * t1;
-        c[5] = (SVS_PF_T2 * 0.25f) * t1 - (SVS_PF_T4 * 0.25f) * t2;
+        const T t1 = X[3] + X[5], t2 = X[3] - X[5];
+        c[3] = splat<T>(SVS_PF_T2 * 0.25f) * t2 + splat<T>(SVS_PF_T4 * 0.25f) * t1;
+        c[5] = splat<T>(SVS_PF_T2 * 0.25f) * t1 - splat<T>(SVS_PF_T4 * 0.25f) * t2;
     }
-    c[4] = X[4] * (SVS_PF_T3 * 0.5f);  // 2 * T3 * 0.25
-    float r[8];
+    c[4] = X[4] * splat<T>(SVS_PF_T3 * 0.5f);  // 2 * T3 * 0.25
+    T r[8];
     rfft8_forward(c, r);
     x[0] = r[0];
     x[7] = r[7];
@@ -487,53 +518,99 @@ SVS_HD void forward_exact(const uint32_t (&rx)[8], const uint32_t (&ry)[8], floa
     for (int u = 0; u < 8; ++u) pf::dct2_8(V[u], D[u]);
 }
 
+// The same 64 coefficients, two lines per operation: the vertical pass transforms column pairs (2p, 2p+1), the
+// horizontal pass row pairs (2q, 2q+1); D2[q][v] = (D[2q][v], D[2q+1][v]).  In between, the 2x2 sub-blocks are
+// transposed in registers.
+SVS_HD void forward_exact_paired(const uint32_t (&rx)[8], const uint32_t (&ry)[8], pf::f32x2 (&D2)[4][8]) {
+    using pf::f32x2;
+    f32x2 V2[4][8];  // V2[p][u] = (V[u][2p], V[u][2p+1])
+#define SVS_COLPAIR(P, W, B0, B1)                                                       \
+    {                                                                                   \
+        f32x2 col[8];                                                                   \
+        _Pragma("unroll") for (int r = 0; r < 8; ++r) {                                 \
+            const f32x2 t = {ubyte_to_float<B0>(W[r]), ubyte_to_float<B1>(W[r])};       \
+            col[r] = t;                                                                 \
+        }                                                                               \
+        pf::dct2_8(col, V2[P]);                                                         \
+    }
+    SVS_COLPAIR(0, rx, 0, 1) SVS_COLPAIR(1, rx, 2, 3) SVS_COLPAIR(2, ry, 0, 1) SVS_COLPAIR(3, ry, 2, 3)
+#undef SVS_COLPAIR
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        f32x2 in[8];
+#pragma unroll
+        for (int p2 = 0; p2 < 4; ++p2) {
+            const f32x2 a = V2[p2][2 * q], b = V2[p2][2 * q + 1];
+            const f32x2 e = {a[0], b[0]}, o = {a[1], b[1]};
+            in[2 * p2] = e;
+            in[2 * p2 + 1] = o;
+        }
+        pf::dct2_8(in, D2[q]);
+    }
+}
+
 // EXACT embed of one block: full DCT -> QIM on 1..n (first nb take payload) -> full IDCT (vertical
 // first, :168) -> clip + truncate (:171).  A block that is entered is always round-tripped, even when
 // nothing is changed (delta <= 0, n = 0): that is what produces the reference's x -> x-1 artefacts.
 template <int U, int QM>
 SVS_HD void embed_block_exact(uint32_t (&rx)[8], uint32_t (&ry)[8], uint32_t n, uint32_t nb, uint32_t hi, uint32_t lo,
                               const QimParams &qp) {
-    float D[8][8];
-    forward_exact(rx, ry, D);
+    using pf::f32x2;
+    f32x2 D2[4][8];
+    forward_exact_paired(rx, ry, D2);
 #pragma unroll
     for (int k = 1; k < 8 * U; ++k) {
         if ((uint32_t)k <= n) {  // wave-uniform
             const int i = k - 1;
             const int bit = (int)window_bit(hi, lo, i);
-            const float c = D[k >> 3][k & 7];
+            const float c = D2[k >> 4][k & 7][(k >> 3) & 1];
             int q = quant_index<QM>(c, qp);
             q += bit - (q & 1);
             float cn;
             if constexpr (QM == QM_DOUBLE) cn = (float)((double)q * qp.delta_d);
             else cn = (float)q * qp.delta_f;
-            D[k >> 3][k & 7] = ((uint32_t)i < nb) ? cn : c;
+            D2[k >> 4][k & 7][(k >> 3) & 1] = ((uint32_t)i < nb) ? cn : c;
         }
     }
-    float P[8][8];  // P[y][v]: vertical inverse of every coefficient column
+    f32x2 P2[4][8];  // vertical inverse of coefficient-column pairs: P2[p][y] = (P[y][2p], P[y][2p+1])
 #pragma unroll
-    for (int v = 0; v < 8; ++v) {
-        const float col[8] = {D[0][v], D[1][v], D[2][v], D[3][v], D[4][v], D[5][v], D[6][v], D[7][v]};
-        float out[8];
-        pf::dct3_8(col, out);
+    for (int p2 = 0; p2 < 4; ++p2) {
+        f32x2 col[8];
 #pragma unroll
-        for (int y = 0; y < 8; ++y) P[y][v] = out[y];
+        for (int q = 0; q < 4; ++q) {
+            const f32x2 a = D2[q][2 * p2], b = D2[q][2 * p2 + 1];
+            const f32x2 e = {a[0], b[0]}, o = {a[1], b[1]};
+            col[2 * q] = e;
+            col[2 * q + 1] = o;
+        }
+        pf::dct3_8(col, P2[p2]);
     }
 #pragma unroll
-    for (int y = 0; y < 8; ++y) {
-        float px[8];
-        pf::dct3_8(P[y], px);
+    for (int q = 0; q < 4; ++q) {  // horizontal inverse of pixel rows 2q, 2q+1
+        f32x2 in[8], px[8];
+#pragma unroll
+        for (int p2 = 0; p2 < 4; ++p2) {
+            const f32x2 a = P2[p2][2 * q], b = P2[p2][2 * q + 1];
+            const f32x2 e = {a[0], b[0]}, o = {a[1], b[1]};
+            in[2 * p2] = e;
+            in[2 * p2 + 1] = o;
+        }
+        pf::dct3_8(in, px);
         // np.uint8(np.clip(v, 0, 255)): floor == trunc on the clipped range, the store saturates
-        uint32_t lo4 = 0, hi4 = 0;  // every byte is overwritten: the input rows are dead after the forward pass
-        lo4 = put_pixel<0>(floorf(px[0]), lo4);
-        lo4 = put_pixel<1>(floorf(px[1]), lo4);
-        lo4 = put_pixel<2>(floorf(px[2]), lo4);
-        lo4 = put_pixel<3>(floorf(px[3]), lo4);
-        hi4 = put_pixel<0>(floorf(px[4]), hi4);
-        hi4 = put_pixel<1>(floorf(px[5]), hi4);
-        hi4 = put_pixel<2>(floorf(px[6]), hi4);
-        hi4 = put_pixel<3>(floorf(px[7]), hi4);
-        rx[y] = lo4;
-        ry[y] = hi4;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            uint32_t lo4 = 0, hi4 = 0;  // every byte is overwritten: the input rows are dead after the forward pass
+            lo4 = put_pixel<0>(floorf(px[0][k]), lo4);
+            lo4 = put_pixel<1>(floorf(px[1][k]), lo4);
+            lo4 = put_pixel<2>(floorf(px[2][k]), lo4);
+            lo4 = put_pixel<3>(floorf(px[3][k]), lo4);
+            hi4 = put_pixel<0>(floorf(px[4][k]), hi4);
+            hi4 = put_pixel<1>(floorf(px[5][k]), hi4);
+            hi4 = put_pixel<2>(floorf(px[6][k]), hi4);
+            hi4 = put_pixel<3>(floorf(px[7][k]), hi4);
+            rx[2 * q + k] = lo4;
+            ry[2 * q + k] = hi4;
+        }
     }
 }
 
