@@ -54,8 +54,9 @@ extern "C" {
  *   0                  FAST transforms: an FMA-factored float32 DCT restricted to the coefficient rows the
  *                      payload touches.  Meets the operator's contract - extracted bits bit-exact, stego PSNR
  *                      within 0.01 dB of the reference - and runs on the HBM roofline.  Stego pixels can differ
- *                      from the reference's where it resolves a rounding tie of c/delta by float32 noise (so can
- *                      bits extracted from frames that were never embedded), and a block that receives no
+ *                      from the reference's where float32 noise decides the outcome - a near-tie of c/delta (so can
+ *                      bits extracted from frames that were never embedded) or a stego value within ~1e-5 of an
+ *                      integer (about 1e-5 of the pixels at n = 3, 1e-3 at n = 10) - and a block that receives no
  *                      coefficient change is left untouched.
  *   SVS_EXACT_POCKETFFT  every float32 operation of scipy.fftpack.dct/idct(norm='ortho') (pocketfft) is
  *                      replayed in order, on all 64 coefficients: stego pixels, tie decisions and the
