@@ -22,6 +22,10 @@ from svsdct import batch as _batch
 from svsdct import framing as _framing
 
 BATCH_FRAMES = int(os.environ.get("SVS_BATCH_FRAMES", "32"))
+# SVS_FUSED_COLOUR=1: colour frames go to the GPU as they are and BGR -> gray -> embed -> BGR runs as ONE kernel
+# (svs_embed_bgr_dev) instead of cv2.cvtColor on the host either side of the operator (:117-126).  Only used when the
+# device conversion reproduces this machine's cv2 bit for bit (svsdct.colour); otherwise the host conversion stays.
+FUSED_COLOUR = os.environ.get("SVS_FUSED_COLOUR", "0") == "1"
 
 
 def _cv2():
@@ -108,6 +112,13 @@ def embed_gambar_ke_video_final(path_video_input, path_gambar_rahasia, path_vide
         return False, None, None
     print(f"    Video output akan disimpan sebagai '{path_out}' (Codec: FFV1).")
 
+    tabel_warna = None
+    if FUSED_COLOUR:
+        from svsdct import colour as _colour
+        try:
+            tabel_warna = _colour.weights_matching_cv2(cv2)
+        except _colour.ColourMismatch as exc:
+            print(f"    Info: jalur warna terfusi tidak dipakai ({exc}).")
     per_frame = _batch.capacity_bits(1, out_h, out_w, num_ac_coeffs)
     usable = per_frame if delta_kuantisasi > 0 else 0              # nothing can be embedded otherwise (:143-145)
     disisipkan, frame_num, selesai = 0, 0, False
@@ -120,14 +131,22 @@ def embed_gambar_ke_video_final(path_video_input, path_gambar_rahasia, path_vide
             ok, frame_bgr = cap.read()
             if not ok:
                 break
-            grays.append(cv2.cvtColor(frame_bgr[0:out_h, 0:out_w], cv2.COLOR_BGR2GRAY))
+            potong = frame_bgr[0:out_h, 0:out_w]
+            grays.append(potong if tabel_warna else cv2.cvtColor(potong, cv2.COLOR_BGR2GRAY))
         if not grays:
             print(f"    Warning: Video selesai sebelum semua payload ({total_bits} bits) disisipkan.")
             break
         stack = np.stack(grays)
         expect = min(len(grays) * usable, total_bits - disisipkan)
-        stego, used = _batch.embed_frames(stack, delta_kuantisasi, num_ac_coeffs, payload,
-                                          bit_offset=disisipkan, n_bits=total_bits - disisipkan)
+        if tabel_warna:
+            stego_bgr, stack, used = _batch.embed_bgr_frames(stack, delta_kuantisasi, num_ac_coeffs, payload,
+                                                             bit_offset=disisipkan, n_bits=total_bits - disisipkan,
+                                                             weights=tabel_warna)
+            stego = stego_bgr[..., 0]
+        else:
+            stego_bgr = None
+            stego, used = _batch.embed_frames(stack, delta_kuantisasi, num_ac_coeffs, payload,
+                                              bit_offset=disisipkan, n_bits=total_bits - disisipkan)
         if used != expect:
             raise RuntimeError(f"embed kernel consumed {used} bits, expected {expect}")
         for k in range(len(grays)):
@@ -135,7 +154,7 @@ def embed_gambar_ke_video_final(path_video_input, path_gambar_rahasia, path_vide
             bits_frame = min(usable, total_bits - disisipkan)
             if frame_num == 1:
                 first_gray, first_stego = stack[0].copy(), stego[0].copy()
-            writer.write(cv2.cvtColor(stego[k], cv2.COLOR_GRAY2BGR))
+            writer.write(stego_bgr[k] if stego_bgr is not None else cv2.cvtColor(stego[k], cv2.COLOR_GRAY2BGR))
             disisipkan += bits_frame
             print(f"    Frame {frame_num}: {bits_frame} bits disisipkan. Total disisipkan: {disisipkan}/{total_bits}")
         if disisipkan >= total_bits:

@@ -21,6 +21,9 @@ from svsdct import framing as _framing
 
 BATCH_FRAMES = int(os.environ.get("SVS_BATCH_FRAMES", "32"))
 _MIN_HEADER_BITS = _framing.HEADER_BITS_STANDARD        # 976 (extract_process.py:51-53)
+# SVS_FUSED_COLOUR=1: bits are extracted straight from the colour frames (svs_extract_bgr_dev) when the device
+# BGR -> gray reproduces this machine's cv2 (svsdct.colour); see embed_process.py
+FUSED_COLOUR = os.environ.get("SVS_FUSED_COLOUR", "0") == "1"
 
 
 def _cv2():
@@ -35,8 +38,11 @@ def _gagal(pesan, cap=None):
     return False
 
 
-def _extract_frames(frames_gray, delta, n_ac):
-    packed, n_bits = _batch.extract_frames(np.stack(frames_gray), delta, n_ac)
+def _extract_frames(frames, delta, n_ac, tabel_warna=None):
+    if tabel_warna:                                            # frames are colour: convert + extract in one kernel
+        packed, n_bits = _batch.extract_bgr_frames(np.stack(frames), delta, n_ac, weights=tabel_warna)
+    else:
+        packed, n_bits = _batch.extract_frames(np.stack(frames), delta, n_ac)
     return np.unpackbits(packed, count=n_bits)
 
 
@@ -60,10 +66,19 @@ def ekstraksi_gambar_video_final(path_stego_video, path_gambar_output,
         cap.release()
         return False
     per_frame = _batch.capacity_bits(1, h, w, num_ac_coeffs)
+    tabel_warna = None
+    if FUSED_COLOUR:
+        from svsdct import colour as _colour
+        try:
+            tabel_warna = _colour.weights_matching_cv2(cv2)
+        except _colour.ColourMismatch as exc:
+            print(f"  Info: jalur warna terfusi tidak dipakai ({exc}).")
 
     def baca_gray():
         ok, frame = cap.read()
-        return cv2.cvtColor(frame[0:h, 0:w], cv2.COLOR_BGR2GRAY) if ok else None
+        if not ok:
+            return None
+        return frame[0:h, 0:w] if tabel_warna else cv2.cvtColor(frame[0:h, 0:w], cv2.COLOR_BGR2GRAY)
 
     print("\n  [Tahap Ekstraksi 1: Membaca Bit Awal dari Video]")
     stream = np.zeros(0, np.uint8)
@@ -76,7 +91,7 @@ def ekstraksi_gambar_video_final(path_stego_video, path_gambar_output,
             cap.release()
             return False
         print(f"    Mengekstrak bit dari frame video ke-{frame_num}...")
-        bits = _extract_frames([gray], delta_kuantisasi, num_ac_coeffs)
+        bits = _extract_frames([gray], delta_kuantisasi, num_ac_coeffs, tabel_warna)
         if bits.size == 0:
             print(f"  Error: Tidak ada bit diekstrak dari frame ke-{frame_num}.")
             cap.release()
@@ -117,7 +132,7 @@ def ekstraksi_gambar_video_final(path_stego_video, path_gambar_output,
             if not grays:
                 print("    Warning: Video selesai sebelum semua ciphertext diekstrak.")
                 break
-            bits = _extract_frames(grays, delta_kuantisasi, num_ac_coeffs)   # one launch for the whole batch
+            bits = _extract_frames(grays, delta_kuantisasi, num_ac_coeffs, tabel_warna)   # one launch per batch
             ct_bits = np.concatenate([ct_bits, bits])
             frame_num += len(grays)
             print(f"    Sisa ciphertext diekstrak sampai frame {frame_num}. "

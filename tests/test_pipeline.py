@@ -130,6 +130,49 @@ def test_payload_spread_over_many_frames_and_batches(monkeypatch, tmp_path, back
     assert np.array_equal(np.asarray(Image.open(str(tmp_path / "o.png"))), secret)
 
 
+@pytest.mark.gpu
+def test_fused_colour_pipelines_equal_host_conversion(monkeypatch, tmp_path, capsys):
+    """SVS_FUSED_COLOUR=1: colour frames go through svs_embed_bgr_dev / svs_extract_bgr_dev after
+    the run-time equality check against the installed cv2 (here the stand-in, which uses the 15-bit table).  The stego
+    video must be byte-identical to the one the host-conversion path writes, and a cv2 whose BGR2GRAY matches no known
+    table must make the pipelines fall back to host conversion."""
+    from svsdct import colour
+    emb, ext = _install(monkeypatch, "gpu")
+    monkeypatch.setattr(emb, "BATCH_FRAMES", 3)
+    frames, secret, secret_path = _make_inputs(tmp_path, n_frames=9, size=(40, 56), secret=(12, 10), seed=21)
+    receiver = fakes.FakeKey(b"bob")
+    pub = fakes.serialisasi_kunci_publik_ecc_compressed(receiver.public())
+    delta, n_ac = 16, 12
+    monkeypatch.setattr(emb.os, "urandom", lambda n: bytes(range(n)))       # same salt and ephemeral key in both runs
+    monkeypatch.setattr(emb, "buat_pasangan_kunci_ecc", lambda: (fakes.FakeKey(b"eph"), fakes.FakeKey(b"eph").public()))
+    assert emb.embed_gambar_ke_video_final("in.mp4", secret_path, str(tmp_path / "host"), delta, n_ac, pub)[0]
+    monkeypatch.setattr(emb, "FUSED_COLOUR", True)
+    monkeypatch.setattr(ext, "FUSED_COLOUR", True)
+    assert colour.weights_matching_cv2(sys.modules["cv2"]) == colour.TABLES["15-bit (OpenCV >= 3.x)"]
+    ok, g0, s0 = emb.embed_gambar_ke_video_final("in.mp4", secret_path, str(tmp_path / "fused"), delta, n_ac, pub)
+    assert ok
+    host, fused = fakes.VIDEOS[str(tmp_path / "host.avi")]["frames"], fakes.VIDEOS[str(tmp_path / "fused.avi")]["frames"]
+    assert len(host) == len(fused) == 9
+    for a, b in zip(host, fused):
+        assert np.array_equal(a, b)
+    assert np.array_equal(s0, fused[0][..., 0]) and np.array_equal(g0, sys.modules["cv2"].cvtColor(frames[0][:40, :56], 6))
+    assert ext.ekstraksi_gambar_video_final(str(tmp_path / "fused.avi"), str(tmp_path / "o.png"), delta, n_ac, receiver)
+    assert np.array_equal(np.asarray(Image.open(str(tmp_path / "o.png"))), secret)
+
+    # an OpenCV whose conversion matches no table: the check raises, the pipelines say so and convert on the host
+    odd = fakes.make_fake_cv2()
+    plain = odd.cvtColor
+    odd.cvtColor = lambda img, code: (plain(img, code) ^ 1) if code == odd.COLOR_BGR2GRAY else plain(img, code)
+    with pytest.raises(colour.ColourMismatch):
+        colour.weights_matching_cv2(odd)
+    monkeypatch.setitem(sys.modules, "cv2", odd)
+    capsys.readouterr()
+    assert emb.embed_gambar_ke_video_final("in.mp4", secret_path, str(tmp_path / "odd"), delta, n_ac, pub)[0]
+    assert "jalur warna terfusi tidak dipakai" in capsys.readouterr().out
+    ext.ekstraksi_gambar_video_final(str(tmp_path / "odd.avi"), str(tmp_path / "o2.png"), delta, n_ac, receiver)
+    assert "jalur warna terfusi tidak dipakai" in capsys.readouterr().out
+
+
 @pytest.mark.parametrize("backend", BACKENDS)
 def test_reference_dummy_configuration(monkeypatch, tmp_path, backend):
     """BASELINE.json configs[0]: the reference's own dummy inputs (config_and_setup.py:225,232-233; defaults
