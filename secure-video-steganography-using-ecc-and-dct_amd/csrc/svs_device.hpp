@@ -170,35 +170,40 @@ __global__ __launch_bounds__(SVS_WG, (U == 2 ? SVS_U2_MIN_WAVES : 1)) void embed
 }
 
 // Tail of the extract kernels: a wavefront's 64*BPL consecutive blocks produce exactly n*BPL aligned
-// 64-bit words of the packed stream.  Each lane drops its flag bytes into the wave-private LDS array
-// `mine`; lanes w < 2*BPL*n then compress 32 flags into one dword and store it.
+// 64-bit words of the packed stream.  The wave assembles them in a private LDS array of big-endian dwords
+// (stream bit p of the wave's chunk = bit 31 - p%32 of dword p/32): every lane ORs its n-bit string in at bit
+// offset lane*BPL*n (ds_or_b32 on at most three dwords), then lanes w < 2*BPL*n byte-swap one dword each and store
+// it.  SVS_WAVE_BITS_DWORDS = dwords per wave incl. slack for the unconditional second / third OR.
+#define SVS_WAVE_BITS_DWORDS(BPL) (2 * (BPL) * 63 + 4)
+
+__device__ __forceinline__ void wave_lds_fence() {  // wave-private LDS: pins the compiler's order, no workgroup barrier
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <int U>
+__device__ __forceinline__ void or_bit_string(uint32_t *mine, uint32_t bit_at, uint32_t hi, uint32_t lo) {
+    // hi:lo = up to 8U-1 bits, MSB-first from bit 63; lands at stream bit `bit_at` of the wave's chunk
+    const uint32_t d = bit_at >> 5, o = bit_at & 31u;
+    atomicOr(&mine[d], hi >> o);
+    atomicOr(&mine[d + 1], __builtin_amdgcn_alignbit(hi, lo, o));           // ({hi,lo} >> o) & 0xffffffff
+    if constexpr (U > 4) atomicOr(&mine[d + 2], __builtin_amdgcn_alignbit(lo, 0u, o));  // o + n > 64 needs n > 32
+}
+
 template <int U, int BPL>
-__device__ __forceinline__ void emit_wave_bits(uint8_t *mine, uint32_t lane, uint64_t wave_first_block, uint32_t n,
+__device__ __forceinline__ void emit_wave_bits(uint32_t *mine, uint32_t lane, uint64_t wave_first_block, uint32_t n,
                                                uint32_t hi_a, uint32_t lo_a, uint32_t hi_b, uint32_t lo_b,
                                                uint8_t *__restrict__ out, uint64_t out_bytes) {
-    // lane writes its n*BPL flag bytes at [lane*BPL*n, ...)
-#pragma unroll
-    for (int i = 0; i < 8 * U - 1; ++i) {
-        if ((uint32_t)i < n) {
-            mine[lane * BPL * n + i] = (uint8_t)window_bit(hi_a, lo_a, i);
-            if constexpr (BPL == 2) mine[(lane * BPL + 1) * n + i] = (uint8_t)window_bit(hi_b, lo_b, i);
-        }
-    }
-    __syncthreads();
-
-    // 64*BPL*n flag bytes -> 2*BPL*n dwords of packed stream; dword w covers flags [32w, 32w+32)
+    const uint32_t words = 2u * BPL * n;  // 64*BPL*n bits
+    for (uint32_t w = lane; w < words + 4u; w += 64u) mine[w] = 0u;
+    wave_lds_fence();
+    or_bit_string<U>(mine, lane * BPL * n, hi_a, lo_a);
+    if constexpr (BPL == 2) or_bit_string<U>(mine, (lane * BPL + 1u) * n, hi_b, lo_b);
+    wave_lds_fence();
     const uint64_t wave_byte0 = wave_first_block * n / 8u;  // multiple of 8 bytes
-    for (uint32_t w = lane; w < 2u * BPL * n; w += 64u) {
-        const uint4 f0 = *reinterpret_cast<const uint4 *>(mine + 32u * w);
-        const uint4 f1 = *reinterpret_cast<const uint4 *>(mine + 32u * w + 16u);
-        // four 0/1 bytes (first flag in the low byte) -> nibble with the first flag as MSB
-#define SVS_NIB(X) ((((X) * 0x08040201u) >> 24) & 0xFu)
-        const uint32_t b0 = (SVS_NIB(f0.x) << 4) | SVS_NIB(f0.y);
-        const uint32_t b1 = (SVS_NIB(f0.z) << 4) | SVS_NIB(f0.w);
-        const uint32_t b2 = (SVS_NIB(f1.x) << 4) | SVS_NIB(f1.y);
-        const uint32_t b3 = (SVS_NIB(f1.z) << 4) | SVS_NIB(f1.w);
-#undef SVS_NIB
-        const uint32_t word = b0 | (b1 << 8) | (b2 << 16) | (b3 << 24);
+    for (uint32_t w = lane; w < words; w += 64u) {
+        const uint32_t word = __builtin_bswap32(mine[w]);  // first stream bit -> MSB of the first byte in memory
         const uint64_t at = wave_byte0 + 4ull * w;
         if (at + 4 <= out_bytes) {
             *reinterpret_cast<uint32_t *>(out + at) = word;
@@ -218,7 +223,7 @@ template <int U, int QM, int BPL, int NFIX = 0>
 __global__ __launch_bounds__(SVS_WG) void extract_kernel(const uint8_t *__restrict__ gray, const Geometry g,
                                                       const QimParams qp, uint8_t *__restrict__ out,
                                                       const uint64_t out_bytes) {
-    __shared__ __attribute__((aligned(16))) uint8_t flags[SVS_WG / 64][64 * 64 * BPL];
+    __shared__ uint32_t flags[SVS_WG / 64][SVS_WAVE_BITS_DWORDS(BPL)];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t tile = tile_id(g.xcd_chunk);
     const uint32_t gblock = (tile * (uint32_t)SVS_WG + threadIdx.x) * BPL;
@@ -286,7 +291,7 @@ template <int U, int QM>
 __global__ __launch_bounds__(SVS_WG) void extract_exact_kernel(const uint8_t *__restrict__ gray, const Geometry g,
                                                             const QimParams qp, uint8_t *__restrict__ out,
                                                             const uint64_t out_bytes) {
-    __shared__ __attribute__((aligned(16))) uint8_t flags[SVS_WG / 64][64 * 64];
+    __shared__ uint32_t flags[SVS_WG / 64][SVS_WAVE_BITS_DWORDS(1)];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t tile = tile_id(g.xcd_chunk);
     const uint32_t gblock = tile * (uint32_t)SVS_WG + threadIdx.x;
@@ -601,7 +606,7 @@ template <int U, int QM>
 __global__ __launch_bounds__(SVS_WG) void extract_bgr_kernel(const uint8_t *__restrict__ bgr, const Geometry g,
                                                           const ColourParams c, const QimParams qp,
                                                           uint8_t *__restrict__ out, const uint64_t out_bytes) {
-    __shared__ __attribute__((aligned(16))) uint8_t flags[SVS_WG / 64][64 * 64];
+    __shared__ uint32_t flags[SVS_WG / 64][SVS_WAVE_BITS_DWORDS(1)];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t tile = tile_id(g.xcd_chunk);
     const uint32_t gblock = tile * (uint32_t)SVS_WG + threadIdx.x;
