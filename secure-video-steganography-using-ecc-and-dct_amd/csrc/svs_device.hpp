@@ -514,6 +514,54 @@ __device__ __forceinline__ void gray8_to_bgr(uint32_t lo4, uint32_t hi4, u32x2 &
     q2.y = __builtin_amdgcn_perm(0u, hi4, 0x03030302u);
 }
 
+// A wave's 64 blocks are 64 x 24 = 1536 consecutive bytes per pixel row (except where the run of blocks wraps to the
+// next block row / frame): seen as 192 units of 8 bytes, unit u = bytes [8*(u%3), +8) of the row of block u/3.
+struct WaveUnits {
+    uint32_t owner[3], part[3];  // of unit lane + 64 j
+    bool live[3];
+};
+__device__ __forceinline__ WaveUnits wave_units(uint32_t lane, uint32_t wave_first, uint32_t total_blocks) {
+    WaveUnits w;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const uint32_t u = lane + 64u * j;
+        w.owner[j] = (u * 171u) >> 9;  // u / 3 for u < 192
+        w.part[j] = u - 3u * w.owner[j];
+        w.live[j] = wave_first + w.owner[j] < total_blocks;
+    }
+    return w;
+}
+
+// Cooperative load of the wave's BGR rows (SVS_BGR_DIRECT_LOAD disables it): every load instruction covers 512
+// contiguous bytes; the rows pass through a wave-private, double-buffered LDS row (2 x 192 units) from which each lane
+// picks its own 24 bytes and converts them to gray.  +6 % in extract_bgr_kernel over lanes loading their own rows at a
+// 24-byte stride (profiles/r01_aux_kernel_rates.txt).
+__device__ __forceinline__ void wave_load_gray(const uint8_t *__restrict__ bgr, const Geometry &g, const ColourParams &c,
+                                               const WaveUnits &wu, uint32_t wave_first, uint32_t lane, u32x2 *rowbuf,
+                                               uint32_t (&ax)[8], uint32_t (&ay)[8]) {
+    u32x2 raw[8][3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const uint8_t *src = bgr + block_offset_bgr(wave_first + wu.owner[j], g, c.in_row_pitch, c.in_frame_pitch) +
+                             8u * wu.part[j];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            u32x2 v; v.x = 0u; v.y = 0u;
+            if (wu.live[j]) v = SVS_LD(reinterpret_cast<const u32x2 *>(src + r * c.in_row_pitch));
+            raw[r][j] = v;
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        u32x2 *buf = rowbuf + (r & 1) * 192;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) buf[lane + 64 * j] = raw[r][j];
+        wave_lds_fence();  // also separates the reads of row r-1 from the writes of row r+1 into the same buffer
+        bgr8_to_gray(buf[3 * lane], buf[3 * lane + 1], buf[3 * lane + 2], c, ax[r], ay[r]);
+    }
+    wave_lds_fence();
+}
+
 // Stego rows leave through a wave-private LDS tile (SVS_BGR_DIRECT_STORE disables it): each lane parks its 8 stego gray
 // bytes per row, then the wave writes the BGR row as 192 consecutive 8-byte units - unit u = bytes [8*(u%3), +8) of the
 // 24-byte row of the wave's block u/3 - so every store instruction covers 512 contiguous bytes instead of 8 bytes in
@@ -533,6 +581,8 @@ __global__ __launch_bounds__(SVS_WG) void embed_bgr_kernel(const uint8_t *__rest
     if (!live) return;
 #endif
     uint32_t ax[8], ay[8];
+    // (loads stay per lane here: the cooperative load of extract_bgr_kernel costs this kernel 24 more live addresses
+    // and 100+ VGPRs for +1 %)
     if (live) {
         const uint8_t *src = bgr_in + block_offset_bgr(gblock, g, c.in_row_pitch, c.in_frame_pitch);
 #pragma unroll
@@ -541,6 +591,8 @@ __global__ __launch_bounds__(SVS_WG) void embed_bgr_kernel(const uint8_t *__rest
             load_bgr_row(src + r * c.in_row_pitch, q0, q1, q2);
             bgr8_to_gray(q0, q1, q2, c, ax[r], ay[r]);
         }
+    }
+    if (live) {
         if (gray_ref != nullptr) {  // the operator's first return value: the gray frame before embedding
             uint8_t *ref = gray_ref + block_offset(gblock, g);
 #pragma unroll
@@ -577,12 +629,11 @@ __global__ __launch_bounds__(SVS_WG) void embed_bgr_kernel(const uint8_t *__rest
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     const uint32_t wave_first = gblock - lane;
+    const WaveUnits wu = wave_units(lane, wave_first, g.total_blocks);
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
-        const uint32_t u = lane + 64u * j;
-        const uint32_t owner = (u * 171u) >> 9;  // u / 3 for u < 192
-        const uint32_t part = u - 3u * owner;
-        if (wave_first + owner >= g.total_blocks) continue;
+        const uint32_t owner = wu.owner[j], part = wu.part[j];
+        if (!wu.live[j]) continue;
         // gray pixels feeding the unit's two dwords (v_perm_b32: selector bytes 0-3 pick from the low gray dword,
         // 4-7 from the high one): part 0 = p0 p0 p0 p1 | p1 p1 p2 p2, part 1 = p2 p3 p3 p3 | p4 p4 p4 p5,
         // part 2 = p5 p5 p6 p6 | p6 p7 p7 p7
@@ -612,9 +663,15 @@ __global__ __launch_bounds__(SVS_WG) void extract_bgr_kernel(const uint8_t *__re
     const uint32_t gblock = tile * (uint32_t)SVS_WG + threadIdx.x;
     const uint32_t n = g.n_ac;
     uint32_t hi = 0, lo = 0;
+    uint32_t ax[8], ay[8];
+#if !defined(SVS_BGR_DIRECT_LOAD)
+    __shared__ __attribute__((aligned(16))) u32x2 rows[SVS_WG / 64][2 * 192];
+    const WaveUnits wu = wave_units(lane, gblock - lane, g.total_blocks);
+    wave_load_gray(bgr, g, c, wu, gblock - lane, lane, &rows[wave][0], ax, ay);
+    if (gblock < g.total_blocks) extract_block_exact<U, QM>(ax, ay, n, qp, hi, lo);
+#else
     if (gblock < g.total_blocks) {
         const uint8_t *src = bgr + block_offset_bgr(gblock, g, c.in_row_pitch, c.in_frame_pitch);
-        uint32_t ax[8], ay[8];
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
             u32x2 q0, q1, q2;
@@ -623,6 +680,7 @@ __global__ __launch_bounds__(SVS_WG) void extract_bgr_kernel(const uint8_t *__re
         }
         extract_block_exact<U, QM>(ax, ay, n, qp, hi, lo);
     }
+#endif
     emit_wave_bits<U, 1>(&flags[wave][0], lane, (uint64_t)tile * (uint32_t)SVS_WG + wave * 64u, n, hi, lo, 0u, 0u, out,
                          out_bytes);
 }
