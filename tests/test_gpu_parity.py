@@ -503,6 +503,54 @@ def test_fused_colour_embed_equals_convert_embed_convert(mode):
     assert used == 50 and np.array_equal(out[..., 0], want)
 
 
+def test_fused_colour_pitched_frames_leave_padding_alone():
+    """Row / frame pitches larger than the frames (both BGR buffers and the gray reference): same pixels as the packed
+    call, padding bytes untouched - the wave-cooperative addressing must never step outside a block row."""
+    rng = np.random.default_rng(5)
+    f, h, w, n_ac, delta = 3, 24, 88, 10, 12          # 11 blocks per row: waves straddle rows and frames
+    bgr = rng.integers(0, 256, (f, h, w, 3), dtype=np.uint8)
+    payload = synth.synthetic_bits(batch.capacity_bits(f, h, w, n_ac) - 5, seed=9)
+    want_bgr, want_gray, want_used = batch.embed_bgr_frames(bgr, delta, n_ac, payload, mode="fast")
+    irp, orp, grp = 3 * w + 24, 3 * w + 8, w + 16
+    ifp, ofp, gfp = irp * h + 64, orp * (h + 2), grp * h + 8
+    src = np.full(f * ifp, 0xA5, np.uint8)
+    for k in range(f):
+        for y in range(h):
+            src[k * ifp + y * irp: k * ifp + y * irp + 3 * w] = bgr[k, y].reshape(-1)
+    d_in, d_out, d_gray = _Dev(src.size), _Dev(f * ofp), _Dev(f * gfp)
+    d_in.put(src)
+    d_out.put(np.full(f * ofp, 0x5A, np.uint8))
+    d_gray.put(np.full(f * gfp, 0x3C, np.uint8))
+    packed = batch.pack_bits(payload)
+    d_bits = _Dev(packed.size)
+    d_bits.put(packed)
+    planes = Planes(n_frames=f, height=h, width=w, row_pitch=grp, frame_pitch=gfp)
+    used = batch.embed_bgr_device(d_in.ptr.value, d_out.ptr.value, d_gray.ptr.value, planes, delta, n_ac,
+                                  d_bits.ptr.value, 0, payload.size, mode="fast", in_pitches=(irp, ifp),
+                                  out_pitches=(orp, ofp))
+    native.check(native.load().svs_stream_synchronize(None), "sync")
+    assert used == want_used
+    out, gray = d_out.get(), d_gray.get()
+    mask_out, mask_gray = np.ones(out.size, bool), np.ones(gray.size, bool)
+    for k in range(f):
+        for y in range(h):
+            a = k * ofp + y * orp
+            assert np.array_equal(out[a: a + 3 * w], want_bgr[k, y].reshape(-1)), (k, y)
+            mask_out[a: a + 3 * w] = False
+            b = k * gfp + y * grp
+            assert np.array_equal(gray[b: b + w], want_gray[k, y]), (k, y)
+            mask_gray[b: b + w] = False
+    assert (out[mask_out] == 0x5A).all() and (gray[mask_gray] == 0x3C).all()
+    # extraction from the pitched stego buffer
+    cap = batch.capacity_bits(f, h, w, n_ac)
+    d_ext = _Dev((cap + 7) // 8 + 8)
+    got = batch.extract_bgr_device(d_out.ptr.value, Planes.contiguous(f, h, w), delta, n_ac, d_ext.ptr.value,
+                                   (cap + 7) // 8 + 8, pitches=(orp, ofp))
+    native.check(native.load().svs_stream_synchronize(None), "sync")
+    want_packed, want_n = batch.extract_bgr_frames(want_bgr, delta, n_ac)
+    assert got == want_n == cap and np.array_equal(d_ext.get()[: want_packed.size], want_packed)
+
+
 def test_fused_colour_argument_checks():
     lib = native.load()
     planes = Planes.contiguous(1, 8, 8)
