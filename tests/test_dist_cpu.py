@@ -30,9 +30,12 @@ def _worker(rank, world, port, shape, n_ac, delta, n_frames, out_dir):
     payload = synth.synthetic_bits(n_frames * cap, seed=3)                 # the shared stream
     frames = synth.synthetic_frames(count, h, w, seed=3, first_frame=first)  # this rank's frames
     off = sdist.payload_bit_offset(first, h, w, n_ac)
-    stego, used = orc.batch_embed(frames, delta, payload[off:off + count * cap], n_ac)
-    assert used == count * cap
-    bits = orc.batch_extract_bits(stego, delta, n_ac)
+    if count:
+        stego, used = orc.batch_embed(frames, delta, payload[off:off + count * cap], n_ac)
+        assert used == count * cap
+        bits = orc.batch_extract_bits(stego, delta, n_ac)
+    else:                                                                  # more ranks than frames: an empty shard
+        bits = np.zeros(0, np.uint8)
     packed = torch.from_numpy(np.packbits(bits)) if bits.size else torch.zeros(0, dtype=torch.uint8)
     got, total = sdist.gather_stream(packed, int(bits.size), dst=0)
     assert total == n_frames * cap
@@ -63,3 +66,11 @@ def test_two_ranks_byte_aligned_streams(tmp_path):
 
 def test_two_ranks_uneven_shards_and_bit_granular_join(tmp_path):
     _run(tmp_path, (24, 40), 3, 5)            # 15 blocks * 3 = 45 bits per frame; 3 + 2 frames
+
+
+def test_three_ranks_with_an_empty_shard_free_tail(tmp_path):
+    _run(tmp_path, (16, 24), 7, 7, world=3)   # 6 blocks * 7 = 42 bits per frame; shards of 3 + 2 + 2 frames
+
+
+def test_more_ranks_than_frames(tmp_path):
+    _run(tmp_path, (16, 16), 5, 2, world=3)   # rank 2 owns no frame and contributes zero bits
