@@ -256,7 +256,7 @@ __global__ __launch_bounds__(SVS_WG) void extract_kernel(const uint8_t *__restri
 // so it is VALU-bound at roughly 40 % of the fast kernel's rate; it exists for bit-identical output.
 // ---------------------------------------------------------------------------------------
 #ifndef SVS_EXACT_MIN_WAVES
-#define SVS_EXACT_MIN_WAVES 3  // waves per SIMD the exact embed kernel is register-allocated for (no scratch; 4 spills 52 B and is 8 % slower)
+#define SVS_EXACT_MIN_WAVES 2  // waves per SIMD the exact embed kernel is register-allocated for (2: +1..3 % over 3; 4 spills 52 B and is 8 % slower)
 #endif
 template <int QM>
 __global__ __launch_bounds__(SVS_WG, SVS_EXACT_MIN_WAVES) void embed_exact_kernel(const uint8_t *__restrict__ gray,
