@@ -763,7 +763,7 @@ int svs_frame_sse_dev(const uint8_t *d_a, const uint8_t *d_b, const svs_planes *
 uint64_t svs_ssim_workspace_bytes(const svs_planes *p) {
     if (!p || p->n_frames <= 0 || p->height < 7 || p->width < 7) return 0;
     const uint64_t gx = ((uint64_t)(p->width - 6) + 255) / 256, gy = ((uint64_t)(p->height - 6) + SVS_SSIM_BAND - 1) / SVS_SSIM_BAND;
-    return (gx * gy + 1) * (uint64_t)p->n_frames * sizeof(double);   // partials + one data_range per frame
+    return (gx * gy + 2) * (uint64_t)p->n_frames * sizeof(double);   // partials + data_range + {min, max} per frame
 }
 
 int svs_frame_ssim_dev(const uint8_t *d_a, const uint8_t *d_b, const svs_planes *planes, const double *d_data_range,
@@ -781,8 +781,16 @@ int svs_frame_ssim_dev(const uint8_t *d_a, const uint8_t *d_b, const svs_planes 
     double *partial = reinterpret_cast<double *>(d_workspace);
     double *range = partial + (uint64_t)gx * gy * planes->n_frames;
     if (!d_data_range) {
-        hipLaunchKernelGGL(svs::frame_range_kernel, dim3((uint32_t)planes->n_frames), dim3(256), 0, st, d_b, planes->height,
-                           planes->width, planes->row_pitch, planes->frame_pitch, range);
+        // {min, max} per frame sit behind the ranges in the workspace: start from {0xffffffff, 0}
+        uint32_t *lohi = reinterpret_cast<uint32_t *>(range + planes->n_frames);
+        SVS_HIP(hipMemsetAsync(lohi, 0xff, sizeof(uint32_t) * 2 * (size_t)planes->n_frames, st));
+        SVS_HIP(hipMemset2DAsync(lohi + 1, 2 * sizeof(uint32_t), 0, sizeof(uint32_t), (size_t)planes->n_frames, st));
+        const uint32_t gr = (uint32_t)((planes->height + SVS_RANGE_ROWS - 1) / SVS_RANGE_ROWS);
+        hipLaunchKernelGGL(svs::frame_minmax_kernel, dim3(gr, (uint32_t)planes->n_frames), dim3(256), 0, st, d_b,
+                           planes->height, planes->width, planes->row_pitch, planes->frame_pitch, lohi);
+        SVS_HIP(hipGetLastError());
+        hipLaunchKernelGGL(svs::frame_range_finish_kernel, dim3((uint32_t)((planes->n_frames + 255) / 256)), dim3(256), 0, st,
+                           lohi, planes->n_frames, range);
         SVS_HIP(hipGetLastError());
         d_data_range = range;
     }

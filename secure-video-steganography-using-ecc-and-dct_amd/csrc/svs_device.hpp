@@ -778,26 +778,48 @@ __global__ void ssim_finish_kernel(const double *__restrict__ partial, int32_t p
     }
 }
 
-// per-frame max - min of a plane (the data_range quirk of evaluation.calc_ssim, evaluation.py:26)
-__global__ __launch_bounds__(256) void frame_range_kernel(const uint8_t *__restrict__ a, int32_t height, int32_t width,
-                                                          int64_t row_pitch, int64_t frame_pitch,
-                                                          double *__restrict__ range) {
-    __shared__ uint32_t lo_s[4], hi_s[4];
-    const int f = blockIdx.x;
-    uint32_t lo = 255, hi = 0;
-    const uint64_t total = (uint64_t)height * width;
-    for (uint64_t i = threadIdx.x; i < total; i += 256) {
-        const uint32_t v = a[(int64_t)f * frame_pitch + (int64_t)(i / width) * row_pitch + (i % width)];
-        lo = min(lo, v); hi = max(hi, v);
+// per-frame max - min of a plane (the data_range quirk of evaluation.calc_ssim, evaluation.py:26), in two steps:
+// workgroups of SVS_RANGE_ROWS rows fold their bytes into lohi[frame] = {min, max} with integer atomics (exact and
+// order-independent), then one thread per frame turns the pair into the double the SSIM kernel reads.
+#define SVS_RANGE_ROWS 16
+__global__ __launch_bounds__(256) void frame_minmax_kernel(const uint8_t *__restrict__ a, int32_t height, int32_t width,
+                                                           int64_t row_pitch, int64_t frame_pitch,
+                                                           uint32_t *__restrict__ lohi) {
+    const int f = blockIdx.y, y0 = blockIdx.x * SVS_RANGE_ROWS;
+    const int w8 = width / 8;  // width is a multiple of 8, rows are 8-byte aligned
+    uint32_t lo = 0x00ff00ffu, hi = 0u;  // two 16-bit lanes each
+    for (int y = y0; y < min(y0 + SVS_RANGE_ROWS, height); ++y) {
+        const u32x2 *row = reinterpret_cast<const u32x2 *>(a + (int64_t)f * frame_pitch + (int64_t)y * row_pitch);
+        for (int c = threadIdx.x; c < w8; c += 256) {
+            const u32x2 v = SVS_LD(row + c);
+            const uint32_t e0 = v.x & 0x00ff00ffu, o0 = (v.x >> 8) & 0x00ff00ffu;
+            const uint32_t e1 = v.y & 0x00ff00ffu, o1 = (v.y >> 8) & 0x00ff00ffu;
+            // packed 16-bit min / max (v_pk_min_u16 / v_pk_max_u16): four bytes per pair of instructions
+            typedef uint16_t u16x2 __attribute__((ext_vector_type(2)));
+            auto pk = [](uint32_t x) { return __builtin_bit_cast(u16x2, x); };
+            u16x2 l = __builtin_elementwise_min(__builtin_elementwise_min(pk(e0), pk(o0)),
+                                                __builtin_elementwise_min(pk(e1), pk(o1)));
+            u16x2 h = __builtin_elementwise_max(__builtin_elementwise_max(pk(e0), pk(o0)),
+                                                __builtin_elementwise_max(pk(e1), pk(o1)));
+            lo = __builtin_bit_cast(uint32_t, __builtin_elementwise_min(pk(lo), l));
+            hi = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(pk(hi), h));
+        }
     }
+    uint32_t mn = min(lo & 0xffffu, lo >> 16), mx = max(hi & 0xffffu, hi >> 16);
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { lo = min(lo, (uint32_t)__shfl_down(lo, o, 64)); hi = max(hi, (uint32_t)__shfl_down(hi, o, 64)); }
-    if ((threadIdx.x & 63) == 0) { lo_s[threadIdx.x >> 6] = lo; hi_s[threadIdx.x >> 6] = hi; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        for (int i = 1; i < 4; ++i) { lo = min(lo, lo_s[i]); hi = max(hi, hi_s[i]); }
-        range[f] = (double)hi - (double)lo;
+    for (int o = 32; o > 0; o >>= 1) {
+        mn = min(mn, (uint32_t)__shfl_down(mn, o, 64));
+        mx = max(mx, (uint32_t)__shfl_down(mx, o, 64));
     }
+    if ((threadIdx.x & 63) == 0) {
+        atomicMin(&lohi[2 * f], mn);
+        atomicMax(&lohi[2 * f + 1], mx);
+    }
+}
+
+__global__ void frame_range_finish_kernel(const uint32_t *__restrict__ lohi, int32_t n_frames, double *__restrict__ range) {
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f < n_frames) range[f] = (double)lohi[2 * f + 1] - (double)lohi[2 * f];
 }
 
 // ---- reference streams for tools/ab_bench.py: what plain copies / reads reach on the same box ----
