@@ -573,9 +573,10 @@ int svs_bgr_to_gray_dev(const uint8_t *d_bgr, int64_t bgr_row_pitch, int64_t bgr
     const uint32_t *w = weights ? weights : dflt;
     if (w[3] < 1 || w[3] > 16 || w[0] + w[1] + w[2] != (1u << w[3]))
         return fail(SVS_ERR_INVALID_ARG, "weights must sum to 2^shift with 1 <= shift <= 16");
-    hipLaunchKernelGGL(svs::bgr_to_gray_kernel, dim3(8192), dim3(256), 0, (hipStream_t)stream, d_bgr, d_gray,
-                       planes->n_frames, planes->height, planes->width, bgr_row_pitch, bgr_frame_pitch,
-                       planes->row_pitch, planes->frame_pitch, w[0], w[1], w[2], w[3]);
+    svs::ColourParams c{bgr_row_pitch, bgr_frame_pitch, 0, 0, w[0], w[1], w[2], w[3]};
+    g.xcd_chunk = kEighth;
+    hipLaunchKernelGGL(svs::bgr_to_gray_kernel, dim3((uint32_t)((total + SVS_WG - 1) / SVS_WG)), dim3(SVS_WG), 0,
+                       (hipStream_t)stream, d_bgr, d_gray, g, c);
     SVS_HIP(hipGetLastError());
     return SVS_OK;
 }
@@ -588,9 +589,10 @@ int svs_gray_to_bgr_dev(const uint8_t *d_gray, const svs_planes *planes, uint8_t
     if (total == 0) return SVS_OK;
     if (!d_gray || ((uintptr_t)d_gray % 8)) return fail(SVS_ERR_INVALID_ARG, "gray pointer NULL or unaligned");
     if (int rc = check_bgr(planes, d_bgr, bgr_row_pitch, bgr_frame_pitch)) return rc;
-    hipLaunchKernelGGL(svs::gray_to_bgr_kernel, dim3(8192), dim3(256), 0, (hipStream_t)stream, d_gray, d_bgr,
-                       planes->n_frames, planes->height, planes->width, planes->row_pitch, planes->frame_pitch,
-                       bgr_row_pitch, bgr_frame_pitch);
+    svs::ColourParams c{0, 0, bgr_row_pitch, bgr_frame_pitch, 0, 0, 0, 0};
+    g.xcd_chunk = kEighth;
+    hipLaunchKernelGGL(svs::gray_to_bgr_kernel, dim3((uint32_t)((total + SVS_WG - 1) / SVS_WG)), dim3(SVS_WG), 0,
+                       (hipStream_t)stream, d_gray, d_bgr, g, c);
     SVS_HIP(hipGetLastError());
     return SVS_OK;
 }

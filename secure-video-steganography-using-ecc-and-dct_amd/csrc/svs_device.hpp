@@ -409,49 +409,8 @@ __global__ __launch_bounds__(256) void bit_errors_kernel(const uint8_t *__restri
 // in because they differ between OpenCV generations (15-bit 3735/19235/9798 today, 14-bit 1868/9617/4899 in
 // older builds) and cv2 is not available to pin either.  4 pixels per thread: 12 bytes in, one dword out.
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void bgr_to_gray_kernel(const uint8_t *__restrict__ bgr, uint8_t *__restrict__ gray,
-                                                          int32_t n_frames, int32_t height, int32_t width,
-                                                          int64_t bgr_row_pitch, int64_t bgr_frame_pitch,
-                                                          int64_t row_pitch, int64_t frame_pitch, uint32_t wb,
-                                                          uint32_t wg, uint32_t wr, uint32_t shift) {
-    const uint32_t quads = (uint32_t)width / 4u;
-    const uint64_t total = (uint64_t)n_frames * height * quads;
-    const uint32_t half = 1u << (shift - 1);
-    for (uint64_t t = (uint64_t)blockIdx.x * 256u + threadIdx.x; t < total; t += (uint64_t)gridDim.x * 256u) {
-        const uint32_t xq = (uint32_t)(t % quads);
-        const uint64_t r = t / quads;
-        const uint32_t y = (uint32_t)(r % (uint32_t)height), f = (uint32_t)(r / (uint32_t)height);
-        const uint32_t *src = reinterpret_cast<const uint32_t *>(bgr + (int64_t)f * bgr_frame_pitch +
-                                                                 (int64_t)y * bgr_row_pitch + 12u * xq);
-        const uint32_t w0 = src[0], w1 = src[1], w2 = src[2];  // B0 G0 R0 B1 | G1 R1 B2 G2 | R2 B3 G3 R3
-        const uint32_t p0 = ((w0 & 0xff) * wb + ((w0 >> 8) & 0xff) * wg + ((w0 >> 16) & 0xff) * wr + half) >> shift;
-        const uint32_t p1 = ((w0 >> 24) * wb + (w1 & 0xff) * wg + ((w1 >> 8) & 0xff) * wr + half) >> shift;
-        const uint32_t p2 = (((w1 >> 16) & 0xff) * wb + (w1 >> 24) * wg + (w2 & 0xff) * wr + half) >> shift;
-        const uint32_t p3 = (((w2 >> 8) & 0xff) * wb + ((w2 >> 16) & 0xff) * wg + (w2 >> 24) * wr + half) >> shift;
-        *reinterpret_cast<uint32_t *>(gray + (int64_t)f * frame_pitch + (int64_t)y * row_pitch + 4u * xq) =
-            p0 | (p1 << 8) | (p2 << 16) | (p3 << 24);
-    }
-}
-
-__global__ __launch_bounds__(256) void gray_to_bgr_kernel(const uint8_t *__restrict__ gray, uint8_t *__restrict__ bgr,
-                                                          int32_t n_frames, int32_t height, int32_t width,
-                                                          int64_t row_pitch, int64_t frame_pitch,
-                                                          int64_t bgr_row_pitch, int64_t bgr_frame_pitch) {
-    const uint32_t quads = (uint32_t)width / 4u;
-    const uint64_t total = (uint64_t)n_frames * height * quads;
-    for (uint64_t t = (uint64_t)blockIdx.x * 256u + threadIdx.x; t < total; t += (uint64_t)gridDim.x * 256u) {
-        const uint32_t xq = (uint32_t)(t % quads);
-        const uint64_t r = t / quads;
-        const uint32_t y = (uint32_t)(r % (uint32_t)height), f = (uint32_t)(r / (uint32_t)height);
-        const uint32_t g = *reinterpret_cast<const uint32_t *>(gray + (int64_t)f * frame_pitch + (int64_t)y * row_pitch + 4u * xq);
-        const uint32_t a = g & 0xff, b = (g >> 8) & 0xff, c = (g >> 16) & 0xff, d = g >> 24;
-        uint32_t *dst = reinterpret_cast<uint32_t *>(bgr + (int64_t)f * bgr_frame_pitch + (int64_t)y * bgr_row_pitch + 12u * xq);
-        dst[0] = a * 0x010101u | (b << 24);
-        dst[1] = b * 0x0101u | (c * 0x0101u << 16);
-        dst[2] = c | (d * 0x010101u << 8);
-    }
-}
-
+// (kernels: bgr_to_gray_kernel / gray_to_bgr_kernel below, after the wave-cooperative row helpers they share with the
+// fused colour path)
 // ---------------------------------------------------------------------------------------
 // Fused colour path ("fused read of 3 B/px"): the frames that carry payload go
 // BGR -> gray -> embed -> BGR in ONE pass - 3 B/pixel read, 3 B/pixel written (+1 for the optional gray
@@ -562,6 +521,73 @@ __device__ __forceinline__ void wave_load_gray(const uint8_t *__restrict__ bgr, 
     wave_lds_fence();
 }
 
+// Gray rows of a wave's 64 blocks -> interleaved BGR with B = G = R, through the wave-private tile `mine` (8 rows x 64
+// lanes of 8 gray bytes): every store instruction covers 512 contiguous bytes.
+__device__ __forceinline__ void wave_store_gray_as_bgr(u32x2 *mine, uint32_t lane, uint32_t gblock, bool live,
+                                                       const uint32_t (&ax)[8], const uint32_t (&ay)[8],
+                                                       uint8_t *__restrict__ bgr_out, const Geometry &g,
+                                                       const ColourParams &c) {
+    if (live) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) { u32x2 v; v.x = ax[r]; v.y = ay[r]; mine[r * 64 + lane] = v; }
+    }
+    wave_lds_fence();  // wave-private tile: LDS operations of one wave execute in order; this pins the compiler's order
+    const uint32_t wave_first = gblock - lane;
+    const WaveUnits wu = wave_units(lane, wave_first, g.total_blocks);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const uint32_t owner = wu.owner[j], part = wu.part[j];
+        if (!wu.live[j]) continue;
+        // gray pixels feeding the unit's two dwords (v_perm_b32: selector bytes 0-3 pick from the low gray dword,
+        // 4-7 from the high one): part 0 = p0 p0 p0 p1 | p1 p1 p2 p2, part 1 = p2 p3 p3 p3 | p4 p4 p4 p5,
+        // part 2 = p5 p5 p6 p6 | p6 p7 p7 p7
+        const uint32_t sel0 = part == 0 ? 0x01000000u : part == 1 ? 0x03030302u : 0x06060505u;
+        const uint32_t sel1 = part == 0 ? 0x02020101u : part == 1 ? 0x05040404u : 0x07070706u;
+        uint8_t *dst = bgr_out + block_offset_bgr(wave_first + owner, g, c.out_row_pitch, c.out_frame_pitch) + 8u * part;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const u32x2 v = mine[r * 64 + owner];
+            u32x2 q;
+            q.x = __builtin_amdgcn_perm(v.y, v.x, sel0);
+            q.y = __builtin_amdgcn_perm(v.y, v.x, sel1);
+            asm volatile("global_store_dwordx2 %0, %1, off sc1\n\ts_nop 1" ::"v"(dst + r * c.out_row_pitch), "v"(q) : "memory");
+        }
+    }
+}
+
+// Stand-alone conversions (svs_bgr_to_gray_dev / svs_gray_to_bgr_dev), block-structured like the operator so that they
+// share its coalesced row movers: 8x8 blocks, one lane per block.
+__global__ __launch_bounds__(SVS_WG) void bgr_to_gray_kernel(const uint8_t *__restrict__ bgr, uint8_t *__restrict__ gray,
+                                                             const Geometry g, const ColourParams c) {
+    __shared__ __attribute__((aligned(16))) u32x2 rows[SVS_WG / 64][2 * 192];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t gblock = tile_id(g.xcd_chunk) * (uint32_t)SVS_WG + threadIdx.x;
+    const WaveUnits wu = wave_units(lane, gblock - lane, g.total_blocks);
+    uint32_t ax[8], ay[8];
+    wave_load_gray(bgr, g, c, wu, gblock - lane, lane, &rows[wave][0], ax, ay);
+    if (gblock < g.total_blocks) {
+        typename RowVec<1>::type v[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) { v[r].x = ax[r]; v[r].y = ay[r]; }
+        store_rows<1>(gray + block_offset(gblock, g), g.row_pitch, v);
+    }
+}
+
+__global__ __launch_bounds__(SVS_WG) void gray_to_bgr_kernel(const uint8_t *__restrict__ gray, uint8_t *__restrict__ bgr,
+                                                             const Geometry g, const ColourParams c) {
+    __shared__ __attribute__((aligned(16))) u32x2 tile[SVS_WG / 64][8][64];
+    const uint32_t gblock = tile_id(g.xcd_chunk) * (uint32_t)SVS_WG + threadIdx.x;
+    const bool live = gblock < g.total_blocks;
+    uint32_t ax[8], ay[8];
+    if (live) {
+        typename RowVec<1>::type v[8];
+        load_rows<1>(gray + block_offset(gblock, g), g.row_pitch, v);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) { ax[r] = v[r].x; ay[r] = v[r].y; }
+    }
+    wave_store_gray_as_bgr(&tile[threadIdx.x >> 6][0][0], threadIdx.x & 63u, gblock, live, ax, ay, bgr, g, c);
+}
+
 // Stego rows leave through a wave-private LDS tile (SVS_BGR_DIRECT_STORE disables it): each lane parks its 8 stego gray
 // bytes per row, then the wave writes the BGR row as 192 consecutive 8-byte units - unit u = bytes [8*(u%3), +8) of the
 // 24-byte row of the wave's block u/3 - so every store instruction covers 512 contiguous bytes instead of 8 bytes in
@@ -619,36 +645,7 @@ __global__ __launch_bounds__(SVS_WG) void embed_bgr_kernel(const uint8_t *__rest
         store_bgr_row(dst + r * c.out_row_pitch, q0, q1, q2);
     }
 #else
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    if (live) {
-#pragma unroll
-        for (int r = 0; r < 8; ++r) { u32x2 v; v.x = ax[r]; v.y = ay[r]; tile[wave][r][lane] = v; }
-    }
-    // wave-private tile: LDS operations of one wave execute in order; the fences only pin the compiler's order
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    const uint32_t wave_first = gblock - lane;
-    const WaveUnits wu = wave_units(lane, wave_first, g.total_blocks);
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-        const uint32_t owner = wu.owner[j], part = wu.part[j];
-        if (!wu.live[j]) continue;
-        // gray pixels feeding the unit's two dwords (v_perm_b32: selector bytes 0-3 pick from the low gray dword,
-        // 4-7 from the high one): part 0 = p0 p0 p0 p1 | p1 p1 p2 p2, part 1 = p2 p3 p3 p3 | p4 p4 p4 p5,
-        // part 2 = p5 p5 p6 p6 | p6 p7 p7 p7
-        const uint32_t sel0 = part == 0 ? 0x01000000u : part == 1 ? 0x03030302u : 0x06060505u;
-        const uint32_t sel1 = part == 0 ? 0x02020101u : part == 1 ? 0x05040404u : 0x07070706u;
-        uint8_t *dst = bgr_out + block_offset_bgr(wave_first + owner, g, c.out_row_pitch, c.out_frame_pitch) + 8u * part;
-#pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            const u32x2 v = tile[wave][r][owner];
-            u32x2 q;
-            q.x = __builtin_amdgcn_perm(v.y, v.x, sel0);
-            q.y = __builtin_amdgcn_perm(v.y, v.x, sel1);
-            asm volatile("global_store_dwordx2 %0, %1, off sc1\n\ts_nop 1" ::"v"(dst + r * c.out_row_pitch), "v"(q) : "memory");
-        }
-    }
+    wave_store_gray_as_bgr(&tile[threadIdx.x >> 6][0][0], threadIdx.x & 63u, gblock, live, ax, ay, bgr_out, g, c);
 #endif
 }
 
