@@ -48,6 +48,15 @@ uint32_t env_chunk(const char *name, uint32_t dflt) {
     return v ? (uint32_t)strtoul(v, nullptr, 10) : dflt;
 }
 
+// Occupancy cap: unused dynamic LDS such that at most `wg_per_cu` workgroups fit the CU's 160 KB (0 = no cap).  The
+// streaming kernels run FASTER with fewer waves in flight than their register count allows (measured sweeps in
+// profiles/r01_ab_occupancy.txt): fewer concurrent row streams per CU.
+uint32_t lds_pad_for(uint32_t wg_per_cu, uint32_t static_lds) {
+    if (wg_per_cu == 0) return 0;
+    const uint32_t per_wg = (160u * 1024u / wg_per_cu) & ~255u;
+    return per_wg > static_lds ? per_wg - static_lds : 0;
+}
+
 int clamp_ac(int n_ac) { return n_ac < 0 ? 0 : (n_ac > 63 ? 63 : n_ac); }
 
 // validates the plane description and fills the kernel geometry
@@ -134,14 +143,21 @@ Tuning extract_tuning(int rows, const svs_planes *p, const void *a) {
     return t;
 }
 
+// default caps (workgroups of 256 threads per CU; 0 = whatever the registers allow).  Only the one-row, two-blocks-per-lane
+// embed kernel gains (+6 % at 5 instead of the 8 its 61 VGPRs allow); every extract kernel, the embed kernels with more
+// rows and the exact kernels are fastest uncapped (tools/occupancy_sweep.sh).
+uint32_t embed_wg_per_cu(int rows, int bpl) { return rows == 1 && bpl == 2 ? 5u : 0u; }
+uint32_t extract_wg_per_cu(int rows) { (void)rows; return 0; }
+
 template <int QM, int BPL>
 int launch_embed(int rows, uint64_t total, hipStream_t st, const uint8_t *gray, uint8_t *stego, const svs::Geometry &g,
                  const svs::QimParams &qp, const uint32_t *bits, uint64_t bit_offset, uint64_t n_bits,
                  uint32_t n_words) {
     const dim3 grid((uint32_t)((total + SVS_WG * BPL - 1) / (SVS_WG * BPL)));
+    const uint32_t lds_pad = lds_pad_for(env_chunk("SVS_EMBED_WG_PER_CU", embed_wg_per_cu(rows, BPL)), 0);
 #define SVS_CASE(R)                                                                                            \
     case R:                                                                                                    \
-        hipLaunchKernelGGL((svs::embed_kernel<R, QM, BPL>), grid, dim3(SVS_WG), 0, st, gray, stego, g, qp, bits, \
+        hipLaunchKernelGGL((svs::embed_kernel<R, QM, BPL>), grid, dim3(SVS_WG), lds_pad, st, gray, stego, g, qp, bits, \
                            bit_offset, n_bits, n_words);                                                       \
         break;
     if constexpr (BPL == 2) {  // two blocks per lane is only instantiated (and only pays) for one coefficient row
@@ -168,16 +184,17 @@ int launch_extract(int rows, uint64_t total, hipStream_t st, const uint8_t *gray
     // (profiles/r01_ab_quant_exact.txt).  The same specialisation of the embed kernel measured SLOWER (-13 % at
     // 600 x 4K, n = 10) and n = 3 gains nothing (HBM-bound), so those stay on the run-time-n kernels.
     const bool fixed_n = env_chunk("SVS_FIXED_N", 1) != 0;   // experiment knob
+    const uint32_t lds_pad = lds_pad_for(env_chunk("SVS_EXTRACT_WG_PER_CU", extract_wg_per_cu(rows)), 4096);
     if constexpr (BPL == 1) {
         if (fixed_n && g.n_ac == 10) {
-            hipLaunchKernelGGL((svs::extract_kernel<2, QM, 1, 10>), grid, dim3(SVS_WG), 0, st, gray, g, qp, out, out_bytes);
+            hipLaunchKernelGGL((svs::extract_kernel<2, QM, 1, 10>), grid, dim3(SVS_WG), lds_pad, st, gray, g, qp, out, out_bytes);
             SVS_HIP(hipGetLastError());
             return SVS_OK;
         }
     }
 #define SVS_CASE(R)                                                                                                  \
     case R:                                                                                                          \
-        hipLaunchKernelGGL((svs::extract_kernel<R, QM, BPL>), grid, dim3(SVS_WG), 0, st, gray, g, qp, out, out_bytes); \
+        hipLaunchKernelGGL((svs::extract_kernel<R, QM, BPL>), grid, dim3(SVS_WG), lds_pad, st, gray, g, qp, out, out_bytes); \
         break;
     if constexpr (BPL == 2) {  // two blocks per lane is only instantiated (and only pays) for one coefficient row
         switch (rows) {
@@ -199,14 +216,15 @@ int launch_embed_exact(int qm, uint64_t total, hipStream_t st, const uint8_t *gr
                        const svs::Geometry &g, const svs::QimParams &qp, const uint32_t *bits, uint64_t bit_offset,
                        uint64_t n_bits, uint32_t n_words) {
     const dim3 grid((uint32_t)((total + SVS_WG - 1) / SVS_WG));
+    const uint32_t lds_pad = lds_pad_for(env_chunk("SVS_EMBED_WG_PER_CU", 0), 0);
     if (qm == svs::QM_DOUBLE)
-        hipLaunchKernelGGL((svs::embed_exact_kernel<svs::QM_DOUBLE>), grid, dim3(SVS_WG), 0, st, gray, stego, g, qp, bits,
+        hipLaunchKernelGGL((svs::embed_exact_kernel<svs::QM_DOUBLE>), grid, dim3(SVS_WG), lds_pad, st, gray, stego, g, qp, bits,
                            bit_offset, n_bits, n_words);
     else if (qm == svs::QM_POW2)
-        hipLaunchKernelGGL((svs::embed_exact_kernel<svs::QM_POW2>), grid, dim3(SVS_WG), 0, st, gray, stego, g, qp, bits,
+        hipLaunchKernelGGL((svs::embed_exact_kernel<svs::QM_POW2>), grid, dim3(SVS_WG), lds_pad, st, gray, stego, g, qp, bits,
                            bit_offset, n_bits, n_words);
     else
-        hipLaunchKernelGGL((svs::embed_exact_kernel<svs::QM_F32>), grid, dim3(SVS_WG), 0, st, gray, stego, g, qp, bits,
+        hipLaunchKernelGGL((svs::embed_exact_kernel<svs::QM_F32>), grid, dim3(SVS_WG), lds_pad, st, gray, stego, g, qp, bits,
                            bit_offset, n_bits, n_words);
     SVS_HIP(hipGetLastError());
     return SVS_OK;
@@ -216,9 +234,10 @@ template <int QM>
 int launch_extract_exact(int rows, uint64_t total, hipStream_t st, const uint8_t *gray, const svs::Geometry &g,
                          const svs::QimParams &qp, uint8_t *out, uint64_t out_bytes) {
     const dim3 grid((uint32_t)((total + SVS_WG - 1) / SVS_WG));
+    const uint32_t lds_pad = lds_pad_for(env_chunk("SVS_EXTRACT_WG_PER_CU", extract_wg_per_cu(rows)), 4096);
 #define SVS_CASE(R)                                                                                                  \
     case R:                                                                                                          \
-        hipLaunchKernelGGL((svs::extract_exact_kernel<R, QM>), grid, dim3(SVS_WG), 0, st, gray, g, qp, out, out_bytes); \
+        hipLaunchKernelGGL((svs::extract_exact_kernel<R, QM>), grid, dim3(SVS_WG), lds_pad, st, gray, g, qp, out, out_bytes); \
         break;
     switch (rows) {
         SVS_CASE(1) SVS_CASE(2) SVS_CASE(3) SVS_CASE(4) SVS_CASE(5) SVS_CASE(6) SVS_CASE(7) SVS_CASE(8)
@@ -241,13 +260,14 @@ int launch_embed_bgr(int rows, uint64_t total, hipStream_t st, const uint8_t *in
                             const svs::Geometry &g, const svs::ColourParams &c, const svs::QimParams &qp,
                             const uint32_t *bits, uint64_t bit_offset, uint64_t n_bits, uint32_t n_words) {
     const dim3 grid((uint32_t)((total + SVS_WG - 1) / SVS_WG));
+    const uint32_t lds_pad = lds_pad_for(env_chunk("SVS_EMBED_BGR_WG_PER_CU", 0), 16384);
     if constexpr (EXACT) {
-        hipLaunchKernelGGL((svs::embed_bgr_kernel<8, QM, true>), grid, dim3(SVS_WG), 0, st, in, out, ref, g, c, qp, bits,
+        hipLaunchKernelGGL((svs::embed_bgr_kernel<8, QM, true>), grid, dim3(SVS_WG), lds_pad, st, in, out, ref, g, c, qp, bits,
                            bit_offset, n_bits, n_words);
     } else {
 #define SVS_CASE(R)                                                                                                   \
     case R:                                                                                                           \
-        hipLaunchKernelGGL((svs::embed_bgr_kernel<R, QM, false>), grid, dim3(SVS_WG), 0, st, in, out, ref, g, c, qp, bits, \
+        hipLaunchKernelGGL((svs::embed_bgr_kernel<R, QM, false>), grid, dim3(SVS_WG), lds_pad, st, in, out, ref, g, c, qp, bits, \
                            bit_offset, n_bits, n_words);                                                              \
         break;
         switch (rows) {

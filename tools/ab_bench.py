@@ -20,6 +20,7 @@ ap.add_argument("--mode", default="fast", choices=["fast", "exact"])
 ap.add_argument("--extract-u1-ab", action="store_true", help="A/B SVS_FAST_EXTRACT_U1=0 vs 1 on the first lib")
 ap.add_argument("--fixed-n-ab", action="store_true", help="A/B SVS_FIXED_N=1 vs 0 on the first lib")
 ap.add_argument("--chunks", default="", help="comma list: sweep SVS_*_XCD_CHUNK on the first lib")
+ap.add_argument("--env-sweep", default="", help="NAME=v1,v2,...: sweep one environment knob on the first lib")
 ap.add_argument("libs", nargs="+")
 a = ap.parse_args()
 FLAGS = 1 if a.mode == "exact" else 0
@@ -33,6 +34,9 @@ def load(path):
 libs = [(os.path.basename(p).replace("libsvsdct", "").replace(".so", "") or "base", load(p), None) for p in a.libs]
 if a.chunks:
     libs = [(f"chunk{c}", libs[0][1], c) for c in a.chunks.split(",")]
+if a.env_sweep:
+    _name, _vals = a.env_sweep.split("=")
+    libs = [(f"{_name}={v}", libs[0][1], "E" + v) for v in _vals.split(",")]
 if a.extract_u1_ab:
     libs = [("exact_fwd", libs[0][1], "X0"), ("fast_fwd", libs[0][1], "X1")]
 if a.fixed_n_ab:
@@ -55,6 +59,8 @@ for r in range(a.rounds + 2):
     for name, lib, chunk in libs:
         if chunk is not None and chunk.startswith("X"):
             os.environ["SVS_FAST_EXTRACT_U1"] = chunk[1]
+        elif chunk is not None and chunk.startswith("E"):
+            os.environ[a.env_sweep.split("=")[0]] = chunk[1:]
         elif chunk is not None and chunk.startswith("F"):
             os.environ["SVS_FIXED_N"] = chunk[1]
         elif chunk is not None:
