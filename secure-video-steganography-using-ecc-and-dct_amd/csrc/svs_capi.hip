@@ -143,10 +143,10 @@ Tuning extract_tuning(int rows, const svs_planes *p, const void *a) {
     return t;
 }
 
-// default caps (workgroups of 256 threads per CU; 0 = whatever the registers allow).  Only the one-row, two-blocks-per-lane
-// embed kernel gains (+6 % at 5 instead of the 8 its 61 VGPRs allow); every extract kernel, the embed kernels with more
-// rows and the exact kernels are fastest uncapped (tools/occupancy_sweep.sh).
-uint32_t embed_wg_per_cu(int rows, int bpl) { return rows == 1 && bpl == 2 ? 5u : 0u; }
+// default caps (workgroups of 256 threads per CU; 0 = whatever the registers allow).  Only the one-row embed kernels gain
+// (+5..6 % at 5 instead of the 8 their registers allow, with one or two blocks per lane); every extract kernel, the embed
+// kernels with more rows, the exact kernels and a plain copy are fastest uncapped (tools/occupancy_sweep.sh).
+uint32_t embed_wg_per_cu(int rows, int bpl) { (void)bpl; return rows == 1 ? 5u : 0u; }
 uint32_t extract_wg_per_cu(int rows) { (void)rows; return 0; }
 
 template <int QM, int BPL>
@@ -846,12 +846,13 @@ int svs_ref_copy_dev(const void *d_src, void *d_dst, uint64_t bytes, int mode, v
     const hipStream_t st = (hipStream_t)stream;
     const auto *s = reinterpret_cast<const svs::u32x4 *>(d_src);
     auto *d = reinterpret_cast<svs::u32x4 *>(d_dst);
-    if (mode == 0) hipLaunchKernelGGL(svs::copy_kernel<0>, dim3((uint32_t)((n16 + 255) / 256)), dim3(256), 0, st, s, d, n16);
-    else if (mode == 3) hipLaunchKernelGGL(svs::copy_kernel<3>, dim3((uint32_t)((n16 + 255) / 256)), dim3(256), 0, st, s, d, n16);
-    else if (mode == 4) hipLaunchKernelGGL(svs::copy_kernel<4>, dim3((uint32_t)((n16 + 255) / 256)), dim3(256), 0, st, s, d, n16);
-    else if (mode == 5) hipLaunchKernelGGL(svs::copy_kernel<5>, dim3((uint32_t)((n16 + 255) / 256)), dim3(256), 0, st, s, d, n16);
-    else if (mode == 1) hipLaunchKernelGGL(svs::copy_kernel<1>, dim3(256 * 8), dim3(256), 0, st, s, d, n16);
-    else hipLaunchKernelGGL(svs::copy_kernel<2>, dim3(256 * 8), dim3(256), 0, st, s, d, n16);
+    const uint32_t pad = lds_pad_for(env_chunk("SVS_COPY_WG_PER_CU", 0), 0);  // experiment knob
+    if (mode == 0) hipLaunchKernelGGL(svs::copy_kernel<0>, dim3((uint32_t)((n16 + 255) / 256)), dim3(256), pad, st, s, d, n16);
+    else if (mode == 3) hipLaunchKernelGGL(svs::copy_kernel<3>, dim3((uint32_t)((n16 + 255) / 256)), dim3(256), pad, st, s, d, n16);
+    else if (mode == 4) hipLaunchKernelGGL(svs::copy_kernel<4>, dim3((uint32_t)((n16 + 255) / 256)), dim3(256), pad, st, s, d, n16);
+    else if (mode == 5) hipLaunchKernelGGL(svs::copy_kernel<5>, dim3((uint32_t)((n16 + 255) / 256)), dim3(256), pad, st, s, d, n16);
+    else if (mode == 1) hipLaunchKernelGGL(svs::copy_kernel<1>, dim3(256 * 8), dim3(256), pad, st, s, d, n16);
+    else hipLaunchKernelGGL(svs::copy_kernel<2>, dim3(256 * 8), dim3(256), pad, st, s, d, n16);
     SVS_HIP(hipGetLastError());
     return SVS_OK;
 }
