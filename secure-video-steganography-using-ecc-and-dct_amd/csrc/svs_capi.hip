@@ -489,7 +489,18 @@ int svs_extract_dev(const uint8_t *d_gray, const svs_planes *planes, double delt
         // HBM-bound; in-process A/B in profiles/r01_ab_quant_exact.txt), so FAST mode uses it too and extraction is
         // bit-identical to the reference for ANY input frame.  With more rows it costs ~17 % and stays opt-in.
         // SVS_FAST_EXTRACT_U1=1 (experiment knob) selects the FMA-factored forward instead.
-        if ((flags & SVS_EXACT_POCKETFFT) || (rows == 1 && env_chunk("SVS_FAST_EXTRACT_U1", 0) == 0)) {
+        if (rows == 1 && !(flags & SVS_EXACT_POCKETFFT) && env_chunk("SVS_EXTRACT_SHUFFLE", 0) == 1) {
+            // layout experiment: LDS-staged tiles, 8 lanes per block, cross-lane vertical pass (svs_device.hpp)
+            const dim3 grid((uint32_t)((total + SVS_WG - 1) / SVS_WG));
+            if (qm == svs::QM_POW2)
+                hipLaunchKernelGGL((svs::extract_shuffle_kernel<svs::QM_POW2>), grid, dim3(SVS_WG), 0, st, d_gray, g, qp,
+                                   d_bits_packed_out, bytes);
+            else
+                hipLaunchKernelGGL((svs::extract_shuffle_kernel<svs::QM_F32>), grid, dim3(SVS_WG), 0, st, d_gray, g, qp,
+                                   d_bits_packed_out, bytes);
+            SVS_HIP(hipGetLastError());
+            rc = SVS_OK;
+        } else if ((flags & SVS_EXACT_POCKETFFT) || (rows == 1 && env_chunk("SVS_FAST_EXTRACT_U1", 0) == 0)) {
             rc = qm == svs::QM_POW2 ? launch_extract_exact<svs::QM_POW2>(rows, total, st, d_gray, g, qp, d_bits_packed_out, bytes)
                                     : launch_extract_exact<svs::QM_F32>(rows, total, st, d_gray, g, qp, d_bits_packed_out, bytes);
         } else if (qm == svs::QM_POW2)

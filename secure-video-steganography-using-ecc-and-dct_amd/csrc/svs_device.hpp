@@ -251,6 +251,87 @@ __global__ __launch_bounds__(SVS_WG) void extract_kernel(const uint8_t *__restri
 }
 
 // ---------------------------------------------------------------------------------------
+// Layout experiment (SVS_EXTRACT_SHUFFLE=1, one coefficient row, FAST arithmetic): the north-star's sketch taken
+// literally - tiles staged in LDS, 8 lanes per block (one pixel row each), the vertical pass as cross-lane (DPP)
+// butterflies, one coefficient per lane.  Kept for the A/B in profiles/r01_ab_layout.txt; the shipped kernels keep a
+// whole block in one lane.
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ float dpp_add(float x, int ctrl_is) {  // x + x from the partner lane
+    // ctrl_is: 0 = xor 1 (quad_perm 1,0,3,2), 1 = xor 2 (quad_perm 2,3,0,1), 2 = mirror inside the 8-lane group
+    const int xi = __builtin_bit_cast(int, x);
+    int yi;
+    if (ctrl_is == 0) yi = __builtin_amdgcn_update_dpp(0, xi, 0xB1, 0xF, 0xF, false);
+    else if (ctrl_is == 1) yi = __builtin_amdgcn_update_dpp(0, xi, 0x4E, 0xF, 0xF, false);
+    else yi = __builtin_amdgcn_update_dpp(0, xi, 0x141, 0xF, 0xF, false);
+    return x + __builtin_bit_cast(float, yi);
+}
+
+template <int QM>
+__global__ __launch_bounds__(SVS_WG) void extract_shuffle_kernel(const uint8_t *__restrict__ gray, const Geometry g,
+                                                               const QimParams qp, uint8_t *__restrict__ out,
+                                                               const uint64_t out_bytes) {
+    __shared__ __attribute__((aligned(16))) u32x2 tiles[SVS_WG / 64][8][64];
+    __shared__ uint32_t words[SVS_WG / 64][SVS_WAVE_BITS_DWORDS(1)];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t tile = tile_id(g.xcd_chunk);
+    const uint32_t gblock = tile * (uint32_t)SVS_WG + threadIdx.x, wave_first = gblock - lane;
+    const uint32_t n = g.n_ac;
+    if (gblock < g.total_blocks) {  // stage the wave's 64 blocks: coalesced 512-byte rows, as in the shipped kernels
+        typename RowVec<1>::type v[8];
+        load_rows<1>(gray + block_offset(gblock, g), g.row_pitch, v);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) tiles[wave][r][lane] = v[r];
+    }
+    uint32_t *mine = &words[wave][0];
+    for (uint32_t w = lane; w < 2u * n + 4u; w += 64u) mine[w] = 0u;
+    wave_lds_fence();
+    const uint32_t r = lane & 7u;
+    // this lane's row of the orthonormal DCT-II matrix: k_r(x) = a(r) cos((2x+1) r pi/16), times a(0) of the vertical pass
+    float kr[8];
+#pragma unroll
+    for (int x = 0; x < 8; ++x)
+        kr[x] = (r == 0 ? 0.35355339059327373f : 0.5f) * __cosf((float)((2 * x + 1) * (int)r) * 0.19634954084936207f) *
+                0.35355339059327373f;
+#pragma unroll 1
+    for (uint32_t p = 0; p < 8; ++p) {
+        const uint32_t blk = 8u * p + (lane >> 3);
+        const u32x2 v = tiles[wave][r][blk];
+        float s[8] = {ubyte_to_float<0>(v.x), ubyte_to_float<1>(v.x), ubyte_to_float<2>(v.x), ubyte_to_float<3>(v.x),
+                      ubyte_to_float<0>(v.y), ubyte_to_float<1>(v.y), ubyte_to_float<2>(v.y), ubyte_to_float<3>(v.y)};
+#pragma unroll
+        for (int x = 0; x < 8; ++x) s[x] = dpp_add(dpp_add(dpp_add(s[x], 0), 1), 2);  // column sums, in every lane
+        float c = s[0] * kr[0];
+#pragma unroll
+        for (int x = 1; x < 8; ++x) c = fmaf(s[x], kr[x], c);
+        // parity of every lane's coefficient as a wave mask (bit 8b + r), regrouped into the pass's 8n stream bits
+        // (block-major, coefficient 1 first) by a second ballot, then ORed into the wave's big-endian words by lane 0
+        const bool odd = r >= 1 && r <= n && wave_first + blk < g.total_blocks && ((uint32_t)quant_index<QM>(c, qp) & 1u);
+        const uint64_t m = __ballot(odd);
+        const uint32_t src = 8u * (lane / n) + (lane % n) + 1u;  // lane i < 8n picks block i / n, coefficient i % n + 1
+        const uint64_t packed = __ballot(lane < 8u * n && ((m >> (src & 63u)) & 1ull));  // stream bit i of the pass = bit i
+        if (lane == 0) {
+            const uint64_t be = __builtin_bitreverse64(packed);  // stream bit 0 -> bit 63
+            const uint32_t at = 8u * p * n, d = at >> 5, o = at & 31u;
+            const uint32_t hi = (uint32_t)(be >> 32), lo = (uint32_t)be;
+            atomicOr(&mine[d], hi >> o);
+            atomicOr(&mine[d + 1], __builtin_amdgcn_alignbit(hi, lo, o));
+            atomicOr(&mine[d + 2], __builtin_amdgcn_alignbit(lo, 0u, o));
+        }
+    }
+    wave_lds_fence();
+    const uint64_t wave_byte0 = ((uint64_t)tile * (uint32_t)SVS_WG + wave * 64u) * n / 8u;
+    for (uint32_t w = lane; w < 2u * n; w += 64u) {
+        const uint32_t word = __builtin_bswap32(mine[w]);
+        const uint64_t at = wave_byte0 + 4ull * w;
+        if (at + 4 <= out_bytes) {
+            *reinterpret_cast<uint32_t *>(out + at) = word;
+        } else {
+            for (uint32_t j = 0; j < 4 && at + j < out_bytes; ++j) out[at + j] = (uint8_t)(word >> (8 * j));
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
 // EXACT-mode kernels (pocketfft-identical arithmetic, svs_block.hpp "EXACT mode"): one block per lane.
 // The embed kernel transforms all 64 coefficients both ways (about 2 700 VALU instructions per block),
 // so it is VALU-bound at roughly 40 % of the fast kernel's rate; it exists for bit-identical output.

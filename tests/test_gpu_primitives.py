@@ -33,3 +33,21 @@ def test_cvt_pk_u8_f32_is_what_the_store_path_assumes():
     with open(os.path.join(REPO, "gpurun_out", "cvt_pk_u8_probe.json"), "w") as fh:
         json.dump({"inputs": [repr(float(v)) for v in vals[-19:]], "outputs": out[-19:].tolist(),
                    "saturates": True, "rounding": "nearest even", "exact_on_integer_valued_input": True}, fh, indent=1)
+
+
+def test_layout_experiment_kernel_gives_the_same_bits(monkeypatch):
+    """The LDS + 8-lanes-per-block + DPP variant of the extract kernel (svs_device.hpp `extract_shuffle_kernel`, kept for the
+    layout A/B in profiles/r01_ab_layout.txt) must produce the bits of the shipped kernel."""
+    import numpy as np
+    from svsdct import batch, native, synth
+    native.ensure_device(0)
+    for (f, h, w, n_ac, delta) in ((3, 64, 136, 3, 8), (2, 40, 72, 7, 16), (1, 8, 8, 1, 8), (5, 24, 1048, 5, 8)):
+        frames = synth.synthetic_frames(f, h, w, seed=n_ac)
+        payload = synth.synthetic_bits(batch.capacity_bits(f, h, w, n_ac), seed=n_ac)
+        stego, _ = batch.embed_frames(frames, delta, n_ac, payload, mode="fast")
+        want, n_bits = batch.extract_frames(stego, delta, n_ac, mode="fast")
+        monkeypatch.setenv("SVS_EXTRACT_SHUFFLE", "1")
+        got, n_got = batch.extract_frames(stego, delta, n_ac, mode="fast")
+        monkeypatch.delenv("SVS_EXTRACT_SHUFFLE")
+        assert n_got == n_bits and np.array_equal(got, want), (f, h, w, n_ac)
+        assert np.array_equal(np.unpackbits(got, count=n_bits), payload)
