@@ -65,11 +65,33 @@ def _cpu_worker(task):
     return time.perf_counter() - t0, int((got != bits).sum())
 
 
+def usable_cpus() -> int:
+    """CPUs this process may actually use: scheduler affinity, further limited by a cgroup CPU quota if one is set
+    (a GPU box hands each job a share of the host, not the 256 logical cores os.cpu_count() reports)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as fh:
+                parts = fh.read().split()
+            if path.endswith("cpu.max"):
+                if parts[0] != "max":
+                    n = min(n, max(1, int(int(parts[0]) / int(parts[1]))))
+            else:
+                quota = int(parts[0])
+                if quota > 0:
+                    with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as fh:
+                        n = min(n, max(1, quota // int(fh.read())))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return max(1, n)
+
+
 def cpu_baseline_all_cores(args):
     """BASELINE.md plan (b): one worker per core over frames.  Runs in worker processes forked BEFORE anything
     touches the GPU.  -> dict for the JSON line."""
     import multiprocessing as mp
-    workers = max(1, min(os.cpu_count() or 1, 32, args.cpu_frames))
+    workers = max(1, min(usable_cpus(), 32, args.cpu_frames))
     per_worker = max(1, args.cpu_frames // workers)
     delta = args.delta if args.delta != int(args.delta) else int(args.delta)
     tasks = [(i * per_worker, per_worker, args.height, args.width, args.n_ac, delta) for i in range(workers)]
@@ -79,8 +101,8 @@ def cpu_baseline_all_cores(args):
     frames = workers * per_worker
     return {"value": frames * args.height * args.width / slowest / 1e6, "unit": "Mpix/s", "cores": workers, "kind": "port",
             "payload_bit_errors": sum(e for _, e in out),
-            "sample": f"{frames} frames of the workload ({per_worker} per worker, {workers} worker processes of "
-                      f"{os.cpu_count()} logical cores), embed + extract with the vectorised scipy.fftpack restatement "
+            "sample": f"{frames} frames of the workload ({per_worker} per worker, {workers} worker processes; the job may use "
+                      f"{usable_cpus()} of the host's {os.cpu_count()} logical CPUs), embed + extract with the vectorised scipy.fftpack restatement "
                       f"(oracle/qim_dct_oracle.py); slowest worker {slowest:.2f} s"}
 
 
