@@ -602,6 +602,39 @@ __device__ __forceinline__ void wave_load_gray(const uint8_t *__restrict__ bgr, 
     wave_lds_fence();
 }
 
+// Same, HALF rows at a time (two rounds of 4 rows): half the registers in flight, for kernels that are short of them
+__device__ __forceinline__ void wave_load_gray_halves(const uint8_t *__restrict__ bgr, const Geometry &g,
+                                                      const ColourParams &c, uint32_t wave_first, uint32_t lane,
+                                                      u32x2 *rowbuf, uint32_t (&ax)[8], uint32_t (&ay)[8]) {
+#pragma unroll 1
+    for (int half = 0; half < 2; ++half) {
+        const WaveUnits wu = wave_units(lane, wave_first, g.total_blocks);
+        u32x2 raw[4][3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const uint8_t *src = bgr + block_offset_bgr(wave_first + wu.owner[j], g, c.in_row_pitch, c.in_frame_pitch) +
+                                 8u * wu.part[j] + (int64_t)(4 * half) * c.in_row_pitch;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                u32x2 v; v.x = 0u; v.y = 0u;
+                if (wu.live[j]) v = SVS_LD(reinterpret_cast<const u32x2 *>(src + r * c.in_row_pitch));
+                raw[r][j] = v;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            u32x2 *buf = rowbuf + (r & 1) * 192;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) buf[lane + 64 * j] = raw[r][j];
+            wave_lds_fence();
+            uint32_t gx, gy;
+            bgr8_to_gray(buf[3 * lane], buf[3 * lane + 1], buf[3 * lane + 2], c, gx, gy);
+            if (half == 0) { ax[r] = gx; ay[r] = gy; } else { ax[4 + r] = gx; ay[4 + r] = gy; }
+        }
+        wave_lds_fence();
+    }
+}
+
 // Gray rows of a wave's 64 blocks -> interleaved BGR with B = G = R, through the wave-private tile `mine` (8 rows x 64
 // lanes of 8 gray bytes): every store instruction covers 512 contiguous bytes.
 __device__ __forceinline__ void wave_store_gray_as_bgr(u32x2 *mine, uint32_t lane, uint32_t gblock, bool live,
@@ -688,8 +721,11 @@ __global__ __launch_bounds__(SVS_WG) void embed_bgr_kernel(const uint8_t *__rest
     if (!live) return;
 #endif
     uint32_t ax[8], ay[8];
-    // (loads stay per lane here: the cooperative load of extract_bgr_kernel costs this kernel 24 more live addresses
-    // and 100+ VGPRs for +1 %)
+#if !defined(SVS_BGR_DIRECT_LOAD) && !defined(SVS_BGR_DIRECT_STORE)
+    // cooperative load, four rows at a time: +5..7 % over per-lane loads at a 24-byte stride in FAST mode (62 -> 78 VGPRs),
+    // neutral in EXACT mode; all eight rows at once cost 100+ VGPRs and gained 1 % (profiles/r01_aux_kernel_rates.txt)
+    wave_load_gray_halves(bgr_in, g, c, gblock - (threadIdx.x & 63u), threadIdx.x & 63u, &tile[threadIdx.x >> 6][0][0], ax, ay);
+#else
     if (live) {
         const uint8_t *src = bgr_in + block_offset_bgr(gblock, g, c.in_row_pitch, c.in_frame_pitch);
 #pragma unroll
@@ -699,6 +735,7 @@ __global__ __launch_bounds__(SVS_WG) void embed_bgr_kernel(const uint8_t *__rest
             bgr8_to_gray(q0, q1, q2, c, ax[r], ay[r]);
         }
     }
+#endif
     if (live) {
         if (gray_ref != nullptr) {  // the operator's first return value: the gray frame before embedding
             uint8_t *ref = gray_ref + block_offset(gblock, g);
