@@ -177,6 +177,16 @@ int svs_extract_bgr_dev(const uint8_t *d_bgr, int64_t bgr_row_pitch, int64_t bgr
                         const svs_planes *planes, const uint32_t *weights, double delta, int n_ac,
                         uint8_t *d_bits_packed_out, uint64_t out_capacity_bytes, uint64_t *n_bits_out, void *stream);
 
+/* Host-pointer forms of the two calls above for tightly packed frames (BGR row pitch 3*width, gray row pitch width):
+ * frames and payload are staged through device memory inside the call, which returns when the results are in the
+ * caller's buffers.  bgr_out / gray_ref_out: [n_frames][height][width][3] resp. [n_frames][height][width];
+ * gray_ref_out may be NULL.  `planes` must describe tightly packed gray planes (pitches width and height*width). */
+int svs_embed_bgr(const uint8_t *bgr, uint8_t *bgr_out, uint8_t *gray_ref_out, const svs_planes *planes,
+                  const uint32_t *weights, double delta, int n_ac, const uint8_t *bits_packed, uint64_t bit_offset,
+                  uint64_t n_bits, uint32_t flags, uint64_t *n_embedded);
+int svs_extract_bgr(const uint8_t *bgr, const svs_planes *planes, const uint32_t *weights, double delta, int n_ac,
+                    uint8_t *bits_packed_out, uint64_t out_capacity_bytes, uint64_t *n_bits_out);
+
 /* ---- measurement helpers (synthetic inputs and on-device checks for bench.py / tests) ------ */
 /* value = lo + hash32(seed, first_frame + f, y, x) % span  - same hash as svsdct/synth.py */
 int svs_fill_synthetic_dev(uint8_t *d_frames, const svs_planes *planes, uint32_t seed,

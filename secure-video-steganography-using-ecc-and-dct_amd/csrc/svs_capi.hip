@@ -749,6 +749,80 @@ int svs_extract_bgr_dev(const uint8_t *d_bgr, int64_t bgr_row_pitch, int64_t bgr
     return SVS_OK;
 }
 
+static int packed_planes_only(const svs_planes *p) {
+    if (p->row_pitch != p->width || p->frame_pitch != (int64_t)p->height * p->width)
+        return fail(SVS_ERR_INVALID_ARG, "the host-pointer colour calls take tightly packed frames");
+    return SVS_OK;
+}
+
+int svs_embed_bgr(const uint8_t *bgr, uint8_t *bgr_out, uint8_t *gray_ref_out, const svs_planes *planes,
+                  const uint32_t *weights, double delta, int n_ac, const uint8_t *bits_packed, uint64_t bit_offset,
+                  uint64_t n_bits, uint32_t flags, uint64_t *n_embedded) {
+    svs::Geometry g;
+    uint64_t total = 0;
+    if (int rc = make_geometry(planes, n_ac, &g, &total)) return rc;
+    if (n_embedded) *n_embedded = 0;
+    if (total == 0) return SVS_OK;
+    if (int rc = packed_planes_only(planes)) return rc;
+    if (!bgr || !bgr_out) return fail(SVS_ERR_INVALID_ARG, "BGR pointer is NULL");
+    const uint64_t px = (uint64_t)planes->n_frames * planes->height * planes->width;
+    const uint64_t cap = total * (uint64_t)g.n_ac;
+    const uint64_t use = n_bits < cap ? n_bits : cap;
+    if (use && !bits_packed) return fail(SVS_ERR_INVALID_ARG, "bits pointer is NULL");
+    const uint64_t bit_bytes = use ? (bit_offset + use + 7) / 8 : 0;
+    const uint64_t bit_alloc = ((bit_bytes + 3) / 4) * 4 + 4;
+    DevBuf d_in, d_out, d_gray, d_bits;
+    SVS_HIP(hipMalloc(&d_in.p, 3 * px));
+    SVS_HIP(hipMalloc(&d_out.p, 3 * px));
+    if (gray_ref_out) SVS_HIP(hipMalloc(&d_gray.p, px));
+    SVS_HIP(hipMalloc(&d_bits.p, bit_alloc));
+    SVS_HIP(hipMemcpy(d_in.p, bgr, 3 * px, hipMemcpyHostToDevice));
+    SVS_HIP(hipMemset(d_bits.p, 0, bit_alloc));
+    if (bit_bytes) SVS_HIP(hipMemcpy(d_bits.p, bits_packed, bit_bytes, hipMemcpyHostToDevice));
+    const int64_t rp = 3 * (int64_t)planes->width, fp = rp * planes->height;
+    uint64_t done = 0;
+    const uint64_t pass_bits = use ? use : (n_bits ? 1 : 0);  // see svs_embed
+    if (int rc = svs_embed_bgr_dev((const uint8_t *)d_in.p, rp, fp, (uint8_t *)d_out.p, rp, fp, (uint8_t *)d_gray.p, planes,
+                                   weights, delta, n_ac, (const uint8_t *)d_bits.p, bit_offset, pass_bits, flags, &done,
+                                   nullptr))
+        return rc;
+    SVS_HIP(hipMemcpy(bgr_out, d_out.p, 3 * px, hipMemcpyDeviceToHost));
+    if (gray_ref_out) SVS_HIP(hipMemcpy(gray_ref_out, d_gray.p, px, hipMemcpyDeviceToHost));
+    SVS_HIP(hipDeviceSynchronize());
+    if (n_embedded) *n_embedded = done;
+    return SVS_OK;
+}
+
+int svs_extract_bgr(const uint8_t *bgr, const svs_planes *planes, const uint32_t *weights, double delta, int n_ac,
+                    uint8_t *bits_packed_out, uint64_t out_capacity_bytes, uint64_t *n_bits_out) {
+    svs::Geometry g;
+    uint64_t total = 0;
+    if (int rc = make_geometry(planes, n_ac, &g, &total)) return rc;
+    if (n_bits_out) *n_bits_out = 0;
+    const uint64_t cap = total * (uint64_t)g.n_ac;
+    if (cap == 0) return SVS_OK;
+    if (int rc = packed_planes_only(planes)) return rc;
+    if (!bgr || !bits_packed_out) return fail(SVS_ERR_INVALID_ARG, "BGR/bits pointer is NULL");
+    const uint64_t bytes = (cap + 7) / 8;
+    if (out_capacity_bytes < bytes)
+        return fail(SVS_ERR_CAPACITY, "extract needs %llu bytes, buffer has %llu", (unsigned long long)bytes,
+                    (unsigned long long)out_capacity_bytes);
+    const uint64_t px = (uint64_t)planes->n_frames * planes->height * planes->width;
+    DevBuf d_in, d_bits;
+    SVS_HIP(hipMalloc(&d_in.p, 3 * px));
+    SVS_HIP(hipMalloc(&d_bits.p, bytes + 8));
+    SVS_HIP(hipMemcpy(d_in.p, bgr, 3 * px, hipMemcpyHostToDevice));
+    const int64_t rp = 3 * (int64_t)planes->width, fp = rp * planes->height;
+    uint64_t got = 0;
+    if (int rc = svs_extract_bgr_dev((const uint8_t *)d_in.p, rp, fp, planes, weights, delta, n_ac, (uint8_t *)d_bits.p,
+                                     bytes + 8, &got, nullptr))
+        return rc;
+    SVS_HIP(hipMemcpy(bits_packed_out, d_bits.p, bytes, hipMemcpyDeviceToHost));
+    SVS_HIP(hipDeviceSynchronize());
+    if (n_bits_out) *n_bits_out = got;
+    return SVS_OK;
+}
+
 int svs_fill_synthetic_dev(uint8_t *d_frames, const svs_planes *planes, uint32_t seed, uint32_t first_frame,
                            uint32_t lo, uint32_t span, void *stream) {
     svs::Geometry g;

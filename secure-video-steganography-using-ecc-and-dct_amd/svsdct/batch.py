@@ -196,24 +196,6 @@ def extract_bgr_device(d_bgr: int, planes: Planes, delta, n_ac, d_bits_out: int,
     return int(got.value)
 
 
-class _Scratch:
-    """Device allocations of one host-level call, released together."""
-
-    def __init__(self):
-        self._ptrs = []
-
-    def alloc(self, nbytes: int) -> int:
-        p = C.c_void_p()
-        native.check(native.load().svs_malloc(C.byref(p), max(8, int(nbytes))), "svs_malloc")
-        self._ptrs.append(p.value)
-        return p.value
-
-    def release(self) -> None:
-        for p in self._ptrs:
-            native.load().svs_free(p)
-        self._ptrs = []
-
-
 def _as_bgr_stack(frames: np.ndarray) -> np.ndarray:
     a = np.asarray(frames)
     if a.dtype != np.uint8 or a.ndim != 4 or a.shape[3] != 3:
@@ -242,22 +224,13 @@ def embed_bgr_frames(frames_bgr: np.ndarray, delta, n_ac, bits, bit_offset: int 
     planes = Planes.contiguous(f, h, w)
     out = np.empty_like(stack)
     gray = np.empty((f, h, w), np.uint8) if want_gray else None
-    mem = _Scratch()
-    try:
-        d_in = mem.alloc(stack.nbytes)
-        d_out = mem.alloc(stack.nbytes)
-        d_gray = mem.alloc(f * h * w) if want_gray else 0
-        d_bits = mem.alloc(packed.nbytes)
-        native.check(lib.svs_memcpy_h2d(d_in, stack.ctypes.data, stack.nbytes, None), "h2d")
-        native.check(lib.svs_memcpy_h2d(d_bits, packed.ctypes.data, packed.nbytes, None), "h2d")
-        used = embed_bgr_device(d_in, d_out, d_gray, planes, delta, n_ac, d_bits, bit_offset, n_bits,
-                                mode=mode or _ENV_MODE or "exact", weights=weights)
-        native.check(lib.svs_memcpy_d2h(out.ctypes.data, d_out, out.nbytes, None), "d2h")
-        if want_gray:
-            native.check(lib.svs_memcpy_d2h(gray.ctypes.data, d_gray, gray.nbytes, None), "d2h")
-        native.check(lib.svs_stream_synchronize(None), "sync")
-    finally:
-        mem.release()
+    keep, wptr = _weights_arg(weights)
+    done = C.c_uint64(0)
+    rc = lib.svs_embed_bgr(stack.ctypes.data, out.ctypes.data, gray.ctypes.data if want_gray else None,
+                           C.byref(planes), wptr, float(delta), int(n_ac), packed.ctypes.data, int(bit_offset),
+                           int(n_bits), mode_flags(mode, "exact"), C.byref(done))
+    native.check(rc, "svs_embed_bgr")
+    used = int(done.value)
     return out, gray, used
 
 
@@ -271,16 +244,12 @@ def extract_bgr_frames(frames_bgr: np.ndarray, delta, n_ac, device: int = 0, wei
     nbytes = max(4, (cap + 7) // 8 + (-((cap + 7) // 8)) % 4)
     out = np.zeros(nbytes, np.uint8)
     planes = Planes.contiguous(f, h, w)
-    mem = _Scratch()
-    try:
-        d_in = mem.alloc(stack.nbytes)
-        d_out = mem.alloc(nbytes)
-        native.check(lib.svs_memcpy_h2d(d_in, stack.ctypes.data, stack.nbytes, None), "h2d")
-        n = extract_bgr_device(d_in, planes, delta, n_ac, d_out, nbytes, weights=weights)
-        native.check(lib.svs_memcpy_d2h(out.ctypes.data, d_out, nbytes, None), "d2h")
-        native.check(lib.svs_stream_synchronize(None), "sync")
-    finally:
-        mem.release()
+    keep, wptr = _weights_arg(weights)
+    got = C.c_uint64(0)
+    rc = lib.svs_extract_bgr(stack.ctypes.data, C.byref(planes), wptr, float(delta), int(n_ac), out.ctypes.data,
+                             nbytes, C.byref(got))
+    native.check(rc, "svs_extract_bgr")
+    n = int(got.value)
     return out[: (n + 7) // 8], n
 
 

@@ -70,6 +70,9 @@ SIGNATURES = {
                                      C.c_double, C.c_int, _u8p, C.c_uint64, C.c_uint64, C.c_uint32, _u64p, C.c_void_p]),
     "svs_extract_bgr_dev": (C.c_int, [_u8p, C.c_int64, C.c_int64, _PL, C.c_void_p, C.c_double, C.c_int, _u8p,
                                        C.c_uint64, _u64p, C.c_void_p]),
+    "svs_embed_bgr": (C.c_int, [_u8p, _u8p, _u8p, _PL, C.c_void_p, C.c_double, C.c_int, _u8p, C.c_uint64, C.c_uint64,
+                                 C.c_uint32, _u64p]),
+    "svs_extract_bgr": (C.c_int, [_u8p, _PL, C.c_void_p, C.c_double, C.c_int, _u8p, C.c_uint64, _u64p]),
     "svs_fill_synthetic_dev": (C.c_int, [_u8p, _PL, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]),
     "svs_fill_bits_dev": (C.c_int, [_u8p, C.c_uint64, C.c_uint32, C.c_uint64, C.c_void_p]),
     "svs_frame_sse_dev": (C.c_int, [_u8p, _u8p, _PL, C.c_void_p, C.c_void_p]),
