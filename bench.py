@@ -343,6 +343,19 @@ def main():
             "value": cpu_mpix, "unit": "Mpix/s", "cores": 1, "kind": "port",
             "sample": f"{m} of the {F} frames, embed {t_embed:.2f} s + extract {t_extract:.2f} s, vectorised "
                       f"scipy.fftpack restatement (oracle/qim_dct_oracle.py), 1 thread"}
+        # context: the reference's own structure - a Python loop over blocks with four SciPy calls per
+        # block - restated literally (oracle.frame_operator_loops), on a 240 x 320 crop of frame 0
+        crop = np.ascontiguousarray(sample[0][:240, :320])
+        cbits = bits[: (240 // 8) * (320 // 8) * min(n_ac, 63)]
+        t0 = time.perf_counter()
+        _, loop_stego, _ = orc.frame_operator_loops(crop, "embed", delta if delta != int(delta) else int(delta),
+                                                    orc.bits_to_str(cbits), n_ac)
+        orc.frame_operator_loops(loop_stego, "extract", delta if delta != int(delta) else int(delta), None, n_ac)
+        t_loop = time.perf_counter() - t0
+        result["cpu_literal_block_loop"] = {
+            "value": crop.size / t_loop / 1e6, "unit": "Mpix/s", "cores": 1, "kind": "port",
+            "sample": f"one 320x240 crop, embed + extract in {t_loop:.2f} s: per-block Python loop with scipy.fftpack calls, "
+                      f"the shape of the reference's own code (context only)"}
         # the other direction: the GPU (fast mode) reading the ORACLE's stego frames must give the oracle's bits
         ref_dev = torch.from_numpy(ref_stego).to(dev)
         planes_m = Planes.contiguous(m, H, W)
