@@ -259,6 +259,53 @@ def test_baseline_config5_shape_8k_delta_sweep(delta):
                                   "payload_bit_errors": ber, "payload_bit_errors_reference": ref_ber}
 
 
+def test_full_baseline_batch_on_device_properties():
+    """BASELINE.json configs[2] at FULL size (600 x 3840x2160, n = 3, delta = 8, full-capacity payload = 233 280 000 bits),
+    device-resident like bench.py, checked through size-independent properties: the payload comes back with zero
+    errors from either transform mode, embedding is deterministic (two runs, zero squared difference), the exact-mode
+    stego extracts to the same stream, and every frame's PSNR sits in the band the quantiser step implies."""
+    lib = native.load()
+    f, h, w, n_ac, delta = 600, 2160, 3840, 3, 8.0
+    planes = Planes.contiguous(f, h, w)
+    cap = batch.capacity_bits(f, h, w, n_ac)
+    nbytes = (cap + 7) // 8 + 8
+    d_gray, d_a, d_b = _Dev(f * h * w), _Dev(f * h * w), _Dev(f * h * w)
+    d_pay, d_x1, d_x2 = _Dev(nbytes), _Dev(nbytes), _Dev(nbytes)
+    d_cnt, d_sse = _Dev(8), _Dev(8 * f)
+    native.check(lib.svs_fill_synthetic_dev(d_gray.ptr, C.byref(planes), 20250620, 0, 16, 224, None), "fill")
+    native.check(lib.svs_memset(d_pay.ptr, 0, nbytes, None), "memset")
+    native.check(lib.svs_fill_bits_dev(d_pay.ptr, cap, 20250620, 0, None), "bits")
+
+    def errors(x):
+        native.check(lib.svs_bit_errors_dev(x.ptr, d_pay.ptr, cap, d_cnt.ptr, None), "ber")
+        return int(d_cnt.get(8, np.uint64)[0])
+
+    def sse(x, y):
+        native.check(lib.svs_frame_sse_dev(x.ptr, y.ptr, C.byref(planes), d_sse.ptr, None), "sse")
+        return d_sse.get(8 * f, np.uint64)
+
+    assert batch.embed_device(d_gray.ptr.value, d_a.ptr.value, planes, delta, n_ac, d_pay.ptr.value, 0, cap, mode="fast") == cap
+    assert batch.extract_device(d_a.ptr.value, planes, delta, n_ac, d_x1.ptr.value, nbytes, mode="fast") == cap
+    assert errors(d_x1) == 0
+    assert batch.embed_device(d_gray.ptr.value, d_b.ptr.value, planes, delta, n_ac, d_pay.ptr.value, 0, cap, mode="fast") == cap
+    assert int(sse(d_a, d_b).sum()) == 0                                     # deterministic
+    per_frame = sse(d_gray, d_a).astype(np.float64)
+    psnr = 10 * np.log10(255.0 ** 2 * h * w / per_frame)
+    assert psnr.min() > 44.5 and psnr.max() < 45.5, (psnr.min(), psnr.max())   # 3 coefficients moved by <= 1.5 delta
+    assert batch.embed_device(d_gray.ptr.value, d_b.ptr.value, planes, delta, n_ac, d_pay.ptr.value, 0, cap, mode="exact") == cap
+    assert batch.extract_device(d_b.ptr.value, planes, delta, n_ac, d_x2.ptr.value, nbytes, mode="exact") == cap
+    assert errors(d_x2) == 0
+    assert batch.extract_device(d_b.ptr.value, planes, delta, n_ac, d_x2.ptr.value, nbytes, mode="fast") == cap
+    assert errors(d_x2) == 0                                                  # fast extract of exact stego
+    exact_vs_fast = sse(d_a, d_b)
+    # fast vs exact stego: +-1 on about a hundred of the 8.3 M pixels of a frame (floor decisions inside float32 noise)
+    assert int(exact_vs_fast.max()) < 2000 and float(exact_vs_fast.mean()) < 400
+    _REPORT["full_baseline_batch"] = {"frames": f, "bits": int(cap), "payload_bit_errors": 0,
+                                      "psnr_db_min_max": [float(psnr.min()), float(psnr.max())],
+                                      "fast_vs_exact_stego_squared_difference_per_frame_mean_max":
+                                          [float(exact_vs_fast.mean()), int(exact_vs_fast.max())]}
+
+
 def test_baseline_config4_shape_clips_sharded_by_frame():
     """BASELINE.json configs[3]: 8 x 1080p clips, one per GPU, extracted bits gathered in rank order.  On the
     one-GPU box the 8 shards run back to back through the same entry points the ranks use (shared payload
