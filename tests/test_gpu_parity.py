@@ -259,13 +259,17 @@ def test_baseline_config5_shape_8k_delta_sweep(delta):
                                   "payload_bit_errors": ber, "payload_bit_errors_reference": ref_ber}
 
 
-def test_full_baseline_batch_on_device_properties():
-    """BASELINE.json configs[2] at FULL size (600 x 3840x2160, n = 3, delta = 8, full-capacity payload = 233 280 000 bits),
+@pytest.mark.parametrize("f,h,w,n_ac,delta,band", [
+    (600, 2160, 3840, 3, 8.0, (44.5, 45.5)),      # BASELINE configs[2], the benchmark workload
+    (300, 1080, 1920, 10, 8.0, (39.8, 40.7)),     # configs[1] (n = 10 is the reference GUI's default)
+    (150, 4320, 7680, 3, 16.0, (38.5, 39.5)),     # one GPU's share of configs[4], the largest delta of its sweep
+])
+def test_full_baseline_batch_on_device_properties(f, h, w, n_ac, delta, band):
+    """BASELINE.json configs at FULL size (e.g. 600 x 3840x2160, n = 3, delta = 8, full-capacity payload = 233 280 000 bits),
     device-resident like bench.py, checked through size-independent properties: the payload comes back with zero
     errors from either transform mode, embedding is deterministic (two runs, zero squared difference), the exact-mode
     stego extracts to the same stream, and every frame's PSNR sits in the band the quantiser step implies."""
     lib = native.load()
-    f, h, w, n_ac, delta = 600, 2160, 3840, 3, 8.0
     planes = Planes.contiguous(f, h, w)
     cap = batch.capacity_bits(f, h, w, n_ac)
     nbytes = (cap + 7) // 8 + 8
@@ -291,17 +295,20 @@ def test_full_baseline_batch_on_device_properties():
     assert int(sse(d_a, d_b).sum()) == 0                                     # deterministic
     per_frame = sse(d_gray, d_a).astype(np.float64)
     psnr = 10 * np.log10(255.0 ** 2 * h * w / per_frame)
-    assert psnr.min() > 44.5 and psnr.max() < 45.5, (psnr.min(), psnr.max())   # 3 coefficients moved by <= 1.5 delta
+    assert psnr.min() > band[0] and psnr.max() < band[1], (psnr.min(), psnr.max())   # set by n and delta alone
     assert batch.embed_device(d_gray.ptr.value, d_b.ptr.value, planes, delta, n_ac, d_pay.ptr.value, 0, cap, mode="exact") == cap
     assert batch.extract_device(d_b.ptr.value, planes, delta, n_ac, d_x2.ptr.value, nbytes, mode="exact") == cap
     assert errors(d_x2) == 0
     assert batch.extract_device(d_b.ptr.value, planes, delta, n_ac, d_x2.ptr.value, nbytes, mode="fast") == cap
     assert errors(d_x2) == 0                                                  # fast extract of exact stego
-    exact_vs_fast = sse(d_a, d_b)
-    # fast vs exact stego: +-1 on about a hundred of the 8.3 M pixels of a frame (floor decisions inside float32 noise)
-    assert int(exact_vs_fast.max()) < 2000 and float(exact_vs_fast.mean()) < 400
-    _REPORT["full_baseline_batch"] = {"frames": f, "bits": int(cap), "payload_bit_errors": 0,
+    exact_vs_fast = sse(d_a, d_b).copy()
+    # the contract between the modes: every frame's PSNR within 0.01 dB (the stego planes differ where float32 noise
+    # decides a floor or a quantiser near-tie - about 1e-5 of the pixels at n = 3, 1e-3 at n = 10)
+    psnr_exact = 10 * np.log10(255.0 ** 2 * h * w / sse(d_gray, d_b).astype(np.float64))
+    assert np.abs(psnr_exact - psnr).max() <= PSNR_TOL_DB, float(np.abs(psnr_exact - psnr).max())
+    _REPORT[f"full_baseline_batch/{w}x{h}x{f}_n{n_ac}_d{delta:g}"] = {"frames": f, "bits": int(cap), "payload_bit_errors": 0,
                                       "psnr_db_min_max": [float(psnr.min()), float(psnr.max())],
+                                      "fast_vs_exact_psnr_delta_db_max": float(np.abs(psnr_exact - psnr).max()),
                                       "fast_vs_exact_stego_squared_difference_per_frame_mean_max":
                                           [float(exact_vs_fast.mean()), int(exact_vs_fast.max())]}
 
