@@ -339,7 +339,7 @@ __global__ __launch_bounds__(SVS_WG) void extract_shuffle_kernel(const uint8_t *
 #ifndef SVS_EXACT_MIN_WAVES
 #define SVS_EXACT_MIN_WAVES 2  // waves per SIMD the exact embed kernel is register-allocated for (2: +1..3 % over 3; 4 spills 52 B and is 8 % slower)
 #endif
-template <int QM>
+template <int QM, int U = 8>  // U: coefficient rows the quantiser loop covers (flat indices 1..n lie in rows < U)
 __global__ __launch_bounds__(SVS_WG, SVS_EXACT_MIN_WAVES) void embed_exact_kernel(const uint8_t *__restrict__ gray,
                                                           uint8_t *__restrict__ stego, const Geometry g,
                                                           const QimParams qp,
@@ -362,7 +362,7 @@ __global__ __launch_bounds__(SVS_WG, SVS_EXACT_MIN_WAVES) void embed_exact_kerne
     for (int r = 0; r < 8; ++r) { ax[r] = v[r].x; ay[r] = v[r].y; }
     uint32_t hi, lo;
     payload_window(bits, n_words, bit_offset + first, hi, lo);
-    embed_block_exact<8, QM>(ax, ay, n, block_budget(first, n_bits, n), hi, lo, qp);
+    embed_block_exact<U, QM>(ax, ay, n, block_budget(first, n_bits, n), hi, lo, qp);
 #pragma unroll
     for (int r = 0; r < 8; ++r) { v[r].x = ax[r]; v[r].y = ay[r]; }
     store_rows<1>(stego + off, g.row_pitch, v);
