@@ -942,6 +942,15 @@ int svs_ref_copy_dev(const void *d_src, void *d_dst, uint64_t bytes, int mode, v
     const auto *s = reinterpret_cast<const svs::u32x4 *>(d_src);
     auto *d = reinterpret_cast<svs::u32x4 *>(d_dst);
     const uint32_t pad = lds_pad_for(env_chunk("SVS_COPY_WG_PER_CU", 0), 0);  // experiment knob
+    if (mode == 6 || mode == 7) {
+        const uint64_t n8 = bytes / 8;
+        const auto *s8 = reinterpret_cast<const svs::u32x2 *>(d_src);
+        auto *d8 = reinterpret_cast<svs::u32x2 *>(d_dst);
+        if (mode == 6) hipLaunchKernelGGL(svs::copy8_kernel<1>, dim3((uint32_t)((n8 + 255) / 256)), dim3(256), pad, st, s8, d8, n8);
+        else hipLaunchKernelGGL(svs::copy8_kernel<0>, dim3((uint32_t)((n8 + 255) / 256)), dim3(256), pad, st, s8, d8, n8);
+        SVS_HIP(hipGetLastError());
+        return SVS_OK;
+    }
     if (mode == 0) hipLaunchKernelGGL(svs::copy_kernel<0>, dim3((uint32_t)((n16 + 255) / 256)), dim3(256), pad, st, s, d, n16);
     else if (mode == 3) hipLaunchKernelGGL(svs::copy_kernel<3>, dim3((uint32_t)((n16 + 255) / 256)), dim3(256), pad, st, s, d, n16);
     else if (mode == 4) hipLaunchKernelGGL(svs::copy_kernel<4>, dim3((uint32_t)((n16 + 255) / 256)), dim3(256), pad, st, s, d, n16);

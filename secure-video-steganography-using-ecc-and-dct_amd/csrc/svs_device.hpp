@@ -937,6 +937,17 @@ __global__ void frame_range_finish_kernel(const uint32_t *__restrict__ lohi, int
     if (f < n_frames) range[f] = (double)lohi[2 * f + 1] - (double)lohi[2 * f];
 }
 
+// 8-byte-per-lane copy (what the one-block-per-lane kernels issue): non-temporal load, write-through or non-temporal store
+template <int SC1>
+__global__ __launch_bounds__(256) void copy8_kernel(const u32x2 *__restrict__ src, u32x2 *__restrict__ dst, uint64_t n8) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (i < n8) {
+        const u32x2 v = __builtin_nontemporal_load(src + i);
+        if constexpr (SC1) asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(dst + i), "v"(v) : "memory");
+        else __builtin_nontemporal_store(v, dst + i);
+    }
+}
+
 // ---- reference streams for tools/ab_bench.py: what plain copies / reads reach on the same box ----
 // mode 0: one 16-byte element per thread, non-temporal;  mode 1: grid-stride, 4 x 16 B in flight per
 // thread, non-temporal;  mode 2: as 1 with default cache policy
