@@ -942,6 +942,13 @@ int svs_ref_copy_dev(const void *d_src, void *d_dst, uint64_t bytes, int mode, v
     const auto *s = reinterpret_cast<const svs::u32x4 *>(d_src);
     auto *d = reinterpret_cast<svs::u32x4 *>(d_dst);
     const uint32_t pad = lds_pad_for(env_chunk("SVS_COPY_WG_PER_CU", 0), 0);  // experiment knob
+    if (mode == 8 || mode == 9) {   // 8: 16-byte loads + 8-byte stores, 9: 8-byte loads + 16-byte stores
+        const dim3 grid((uint32_t)((bytes / 16 + 255) / 256));
+        if (mode == 8) hipLaunchKernelGGL(svs::copy_mixed_kernel<1>, grid, dim3(256), 0, st, (const uint8_t *)d_src, (uint8_t *)d_dst, bytes);
+        else hipLaunchKernelGGL(svs::copy_mixed_kernel<0>, grid, dim3(256), 0, st, (const uint8_t *)d_src, (uint8_t *)d_dst, bytes);
+        SVS_HIP(hipGetLastError());
+        return SVS_OK;
+    }
     if (mode == 6 || mode == 7) {
         const uint64_t n8 = bytes / 8;
         const auto *s8 = reinterpret_cast<const svs::u32x2 *>(d_src);

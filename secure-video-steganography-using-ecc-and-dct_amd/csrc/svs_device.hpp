@@ -948,6 +948,36 @@ __global__ __launch_bounds__(256) void copy8_kernel(const u32x2 *__restrict__ sr
     }
 }
 
+// mixed widths: which side of a copy is sensitive to the 8-byte access width?  SPLIT_LOAD: lane-strided 8-byte loads
+// (lane i reads elements i and i + 64 of its wave's 1 KB) + one 16-byte store after a swap through LDS is not needed for
+// the probe: the two halves are simply stored where they belong with the other width.
+template <int WIDE_LOAD>
+__global__ __launch_bounds__(256) void copy_mixed_kernel(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, uint64_t bytes) {
+    // each wave moves 1 KB: either 64 x 16-byte loads + 2 x (64 x 8-byte) stores, or 2 x (64 x 8-byte) loads + 64 x 16-byte stores
+    const uint64_t wave_base = ((uint64_t)blockIdx.x * 256u + (threadIdx.x & ~63u)) * 16u;
+    const uint32_t lane = threadIdx.x & 63u;
+    if (wave_base + 1024 > bytes) return;
+    __shared__ __attribute__((aligned(16))) u32x4 buf[4][64];
+    u32x4 *mine = buf[threadIdx.x >> 6];
+    if constexpr (WIDE_LOAD) {
+        mine[lane] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(src + wave_base) + lane);
+        wave_lds_fence();
+        const u32x2 *as8 = reinterpret_cast<const u32x2 *>(mine);
+        const u32x2 a = as8[lane], b = as8[lane + 64];
+        u32x2 *out = reinterpret_cast<u32x2 *>(dst + wave_base);
+        asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(out + lane), "v"(a) : "memory");
+        asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(out + lane + 64), "v"(b) : "memory");
+    } else {
+        const u32x2 *in = reinterpret_cast<const u32x2 *>(src + wave_base);
+        u32x2 *as8 = reinterpret_cast<u32x2 *>(mine);
+        as8[lane] = __builtin_nontemporal_load(in + lane);
+        as8[lane + 64] = __builtin_nontemporal_load(in + lane + 64);
+        wave_lds_fence();
+        const u32x4 v = mine[lane];
+        asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(reinterpret_cast<u32x4 *>(dst + wave_base) + lane), "v"(v) : "memory");
+    }
+}
+
 // ---- reference streams for tools/ab_bench.py: what plain copies / reads reach on the same box ----
 // mode 0: one 16-byte element per thread, non-temporal;  mode 1: grid-stride, 4 x 16 B in flight per
 // thread, non-temporal;  mode 2: as 1 with default cache policy

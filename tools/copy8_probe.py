@@ -7,10 +7,10 @@ lib.svs_ref_copy_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.
 n = 600 * 2160 * 3840
 a = torch.randint(0, 255, (n,), dtype=torch.uint8, device="cuda"); b = torch.empty_like(a)
 st = torch.cuda.current_stream().cuda_stream
-for name, mode in (("16B nt->nt", 0), ("16B nt->sc1", 3), ("8B nt->sc1", 6), ("8B nt->nt", 7)):
+for name, mode in (("16B nt->nt", 0), ("16B nt->sc1", 3), ("8B nt->sc1", 6), ("8B nt->nt", 7), ("16B ld + 8B sc1 st", 8), ("8B ld + 16B sc1 st", 9)):
     ts = []
     for r in range(9):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(); assert lib.svs_ref_copy_dev(a.data_ptr(), b.data_ptr(), n, mode, st) == 0; e1.record(); torch.cuda.synchronize()
         if r >= 2: ts.append(e0.elapsed_time(e1))
-    print(f"{name:12s} med {statistics.median(ts):.4f} ms -> {2*n/statistics.median(ts)/1e6:7.1f} GB/s", bool(torch.equal(a, b)))
+    print(f"{name:20s} med {statistics.median(ts):.4f} ms -> {2*n/statistics.median(ts)/1e6:7.1f} GB/s", bool(torch.equal(a, b)))
