@@ -313,6 +313,28 @@ def test_full_baseline_batch_on_device_properties(f, h, w, n_ac, delta, band):
                                           [float(exact_vs_fast.mean()), int(exact_vs_fast.max())]}
 
 
+def test_extreme_quantiser_steps():
+    """delta from 1e-3 to 3.3e7 (incl. values float32 cannot represent): EXACT mode stays bit-identical to the oracle -
+    stego pixels, bit counts and the bits read back from the oracle's stego - and FAST mode stays identical to the CPU
+    build of the kernel header.  (FAST extraction against the oracle is not asserted at tiny delta: once delta/2 is
+    below the float32 noise of an 8x8 DCT, two implementations legitimately disagree - as the reference does with itself
+    after the uint8 store.)"""
+    rng = np.random.default_rng(3)
+    frames = rng.integers(0, 256, (2, 32, 48), dtype=np.uint8)
+    for delta in (0.001, 0.01, 0.1, 0.3, 1 / 3, 255.5, 1e3, 1e4, 1e6, 3.3e7):
+        for n_ac in (3, 10, 63):
+            cap = batch.capacity_bits(2, 32, 48, n_ac)
+            bits = rng.integers(0, 2, cap).astype(np.uint8)
+            ref, used = orc.batch_embed(frames, delta, bits, n_ac)
+            stego, got_used = batch.embed_frames(frames, delta, n_ac, bits, mode="exact")
+            assert got_used == used and np.array_equal(stego, ref), (delta, n_ac)
+            packed, n_bits = batch.extract_frames(ref, delta, n_ac, mode="exact")
+            assert np.array_equal(np.unpackbits(packed, count=n_bits), orc.batch_extract_bits(ref, delta, n_ac)), (delta, n_ac)
+            fast, fast_used = batch.embed_frames(frames, delta, n_ac, bits, mode="fast")
+            want, want_used = emu_embed(frames, delta, n_ac, bits)
+            assert fast_used == want_used and np.array_equal(fast, want), (delta, n_ac)
+
+
 def test_baseline_config4_shape_clips_sharded_by_frame():
     """BASELINE.json configs[3]: 8 x 1080p clips, one per GPU, extracted bits gathered in rank order.  On the
     one-GPU box the 8 shards run back to back through the same entry points the ranks use (shared payload
