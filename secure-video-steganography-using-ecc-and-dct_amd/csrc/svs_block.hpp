@@ -264,7 +264,22 @@ struct QimParams {
     float delta_f;      // (float)delta  - divisor
     float inv_delta_f;  // 1 / delta_f   - exact when delta is a power of two (QM_POW2)
     double delta_d;     // delta         - multiplier when (double)delta_f != delta (QM_DOUBLE)
+    float tie_slope;    // FAST extraction: c00 * tie_slope bounds |c_fast/delta - c_pocketfft/delta| (see TIE_SLOPE)
+    float pad;
 };
+
+// FAST extraction and rounding ties.  The FMA-factored forward transform (forward_rows) and pocketfft's are two float32
+// evaluations of the same 64-term sums; for pixels in [0, 255] they differ by at most
+//        |c_fast - c_pf| <= TIE_SLOPE * c00,     c00 = DC coefficient = (sum of the block's pixels) / 8,
+// a forward error bound derived (and printed per coefficient row count) by tools/tie_bound.py: both algorithms are linear
+// in the non-negative pixels, every path from a pixel to the output collects at most m factors (1 + d), |d| <= 2^-24, so
+// the error is at most gamma_m * (sum of |path weights|) * (sum of pixels).  The largest slope over all coefficient
+// indices and all U is 177 * 2^-24 = 1.055e-5; the constant below adds the roundings of the quantiser input itself
+// (c * (1/delta): 3 more factors on |c| <= 2 c00) and 1 % of slack.  extract_block() reports a block in which some
+// c/delta lies within that distance of a half-integer; the kernel then recomputes the block with the pocketfft-identical
+// transform (extract_block_exact) - so FAST extraction returns the reference's bits for ANY input, ties included, while
+// stego frames (coefficients sit near multiples of delta, far from ties) never take the second path.
+#define SVS_TIE_SLOPE (1.055e-5 * 1.01 + 8.0 * 5.9604644775390625e-8)
 
 // How the quantiser is evaluated (all three give the reference's result, they differ in cost):
 //   QM_F32    general delta: IEEE float32 division (about 10 instructions), float32 requantisation
@@ -328,13 +343,27 @@ SVS_HD uint32_t block_budget(uint64_t first, uint64_t n_bits, uint32_t n) {
 // NFIX > 0 fixes the coefficient count at compile time (the two everyday settings, n = 3 of the benchmark and
 // n = 10 of the reference's GUI default, get their own instantiation): transform outputs nobody reads and inverse
 // inputs that are known zeros then disappear from the code.  NFIX = 0 reads n at run time.
+//
+// Returns true when the block has to be REPLAYED with the pocketfft-identical arithmetic (embed_block_exact) instead of
+// keeping this function's result - the caller then leaves the block's pixels as they were and hands it to the replay
+// pass.  Why: the reference transforms every block it enters forth and back (config_and_setup.py:166-171), so a pixel
+// whose exact change is an INTEGER (zero included) is decided by the float32 noise of pocketfft's round trip
+// (x - 1e-5 truncates to x - 1: 128 -> 127 on untouched flat blocks), which only that arithmetic reproduces.
+// For generic blocks a change on the integer grid is a 1e-5 coincidence; it is systematic - all or many pixels of the
+// block - exactly when the changes are "structured": every applied coefficient k has change_k == 0 or c_k == 0 (then
+// change_k is 0 or a multiple of delta, and sums of such terms cancel on whole rows / diagonals of the block: flat
+// areas, letterbox bars, blocks with purely vertical structure at n <= 7).  Flat indices 4 / 32 / 36 (basis +-1/8:
+// changes there are rational whatever c is) do not count as unstructured.  The test is on EXACT zeros: with integer
+// pixels a coefficient of any other index vanishes only through exact cancellations of equal column / row sums (the
+// cosines involved are linearly independent over the rationals), and those survive the float32 factorisation below.
 template <int U, int QM, int NFIX = 0>
-SVS_HD void embed_block(uint32_t (&rx)[8], uint32_t (&ry)[8], uint32_t n_rt, uint32_t nb, uint32_t hi, uint32_t lo,
+SVS_HD bool embed_block(uint32_t (&rx)[8], uint32_t (&ry)[8], uint32_t n_rt, uint32_t nb, uint32_t hi, uint32_t lo,
                         const QimParams &qp) {
     static_assert(NFIX == 0 || (U <= 2 && NFIX / 8 + 1 == U), "NFIX must lie in coefficient row U-1, U <= 2");
     const uint32_t n = NFIX ? (uint32_t)NFIX : n_rt;
     float D[U][8];
     forward_rows<U>(rx, ry, D);
+    float moved = 0.0f;  // sum of |c_k * change_k| over the applied coefficients other than flat indices 4 / 32 / 36
 
     // QIM on flat coefficients 1..n: force the parity of round(c/delta) to the payload bit by
     // +1 (bit 1) / -1 (bit 0), requantise (config_and_setup.py:146-156); keep only the change.
@@ -352,6 +381,7 @@ SVS_HD void embed_block(uint32_t (&rx)[8], uint32_t (&ry)[8], uint32_t n_rt, uin
             if constexpr (QM == QM_DOUBLE) cn = (float)((double)q * qp.delta_d);
             else cn = (float)q * qp.delta_f;
             change = ((uint32_t)i < nb) ? cn - c : 0.0f;
+            if (k != 4 && k != 32 && k != 36) moved = fmaf(fabsf(change), fabsf(c), moved);
         }
         D[u][v] = change;
     }
@@ -416,26 +446,37 @@ SVS_HD void embed_block(uint32_t (&rx)[8], uint32_t (&ry)[8], uint32_t n_rt, uin
         SVS_OUTCOL(4, ry, 0) SVS_OUTCOL(5, ry, 1) SVS_OUTCOL(6, ry, 2) SVS_OUTCOL(7, ry, 3)
 #undef SVS_OUTCOL
     }
+    return nb > 0 && moved == 0.0f;  // nb == 0: the reference never enters the block (:130,:132)
 }
 
-// Parity bits of round(c_k/delta), k = 1..n, MSB-first into hi:lo (config_and_setup.py:160-161)
+// Parity bits of round(c_k/delta), k = 1..n, MSB-first into hi:lo (config_and_setup.py:160-161).
+// Returns true when some c_k/delta is so close to a rounding tie that the reference's own float32 coefficients could
+// round the other way (see SVS_TIE_SLOPE): the caller must then redo the block with extract_block_exact.  When it returns
+// false the bits ARE the reference's, so the quantiser needs no division here: t = c * (1/delta) is within the band of
+// fl(c_pf / delta) as well.
 template <int U, int QM, int NFIX = 0>
-SVS_HD void extract_block(const uint32_t (&rx)[8], const uint32_t (&ry)[8], uint32_t n_rt, const QimParams &qp,
+SVS_HD bool extract_block(const uint32_t (&rx)[8], const uint32_t (&ry)[8], uint32_t n_rt, const QimParams &qp,
                           uint32_t &hi, uint32_t &lo) {
     const uint32_t n = NFIX ? (uint32_t)NFIX : n_rt;
     float D[U][8];
     forward_rows<U>(rx, ry, D);
     hi = 0;
     lo = 0;
+    float off = 0.0f;  // largest |t - round(t)| over the used coefficients (0.5 = exactly on a tie)
 #pragma unroll
     for (int k = 1; k < 8 * U; ++k) {
         if ((uint32_t)k <= n) {  // wave-uniform
-            const uint32_t bit = (uint32_t)quant_index<QM>(D[k >> 3][k & 7], qp) & 1u;
+            const float t = D[k >> 3][k & 7] * qp.inv_delta_f;
+            const float r = rintf(t);
+            off = fmaxf(off, fabsf(t - r));
+            const uint32_t bit = (uint32_t)(int)r & 1u;
             const int i = k - 1;
             if (i < 32) hi |= bit << ((31 - i) & 31);
             else lo |= bit << ((63 - i) & 31);
         }
     }
+    // |t| beyond 2^23 has no fractional part (off == 0) and no tie; NaN cannot occur (finite pixels, delta > 0)
+    return off >= 0.5f - fmaf(D[0][0], qp.tie_slope, 0x1p-20f);
 }
 
 // =====================================================================================================
@@ -754,5 +795,18 @@ SVS_HD void extract_block_exact(const uint32_t (&rx)[8], const uint32_t (&ry)[8]
 }
 
 inline int rows_for(int n) { return (n >> 3) + 1; }  // coefficient rows holding flat indices 1..n
+
+// quantiser parameters and the cheapest exact evaluation mode for this delta (QuantMode); host side
+inline int make_qim(double delta, QimParams *qp) {
+    qp->delta_f = (float)delta;
+    qp->inv_delta_f = 1.0f / qp->delta_f;
+    qp->delta_d = delta;
+    qp->tie_slope = (float)(SVS_TIE_SLOPE / (double)qp->delta_f) * 1.0000002f;  // rounded up
+    qp->pad = 0.0f;
+    if ((double)qp->delta_f != delta) return QM_DOUBLE;
+    int e = 0;
+    const bool pow2 = frexp(delta, &e) == 0.5 && e > -100 && e < 100;
+    return pow2 ? QM_POW2 : QM_F32;
+}
 
 }  // namespace svs

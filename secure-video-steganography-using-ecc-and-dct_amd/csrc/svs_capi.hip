@@ -111,16 +111,7 @@ bool rows_allow_two_blocks(const svs_planes *p, const void *a, const void *b) {
            ((uintptr_t)a % 16 == 0) && (b == nullptr || (uintptr_t)b % 16 == 0);
 }
 
-// quantiser parameters and the cheapest exact evaluation mode for this delta (svs::QuantMode)
-int make_qim(double delta, svs::QimParams *qp) {
-    qp->delta_f = (float)delta;
-    qp->inv_delta_f = 1.0f / qp->delta_f;
-    qp->delta_d = delta;
-    if ((double)qp->delta_f != delta) return svs::QM_DOUBLE;
-    int e = 0;
-    const bool pow2 = std::frexp(delta, &e) == 0.5 && e > -100 && e < 100;
-    return pow2 ? svs::QM_POW2 : svs::QM_F32;
-}
+using svs::make_qim;
 
 struct Tuning {
     bool two_blocks;
@@ -149,16 +140,22 @@ Tuning extract_tuning(int rows, const svs_planes *p, const void *a) {
 uint32_t embed_wg_per_cu(int rows, int bpl) { (void)bpl; return rows == 1 ? 5u : 0u; }
 uint32_t extract_wg_per_cu(int rows) { (void)rows; return 0; }
 
+// 64-bit words of the replay map an embed launch over `total` blocks writes (one per wave and block-of-the-lane)
+uint64_t replay_map_words(uint64_t total, int bpl) {
+    const uint64_t grid = (total + SVS_WG * bpl - 1) / (SVS_WG * bpl);
+    return grid * (SVS_WG / 64) * bpl;
+}
+
 template <int QM, int BPL>
 int launch_embed(int rows, uint64_t total, hipStream_t st, const uint8_t *gray, uint8_t *stego, const svs::Geometry &g,
                  const svs::QimParams &qp, const uint32_t *bits, uint64_t bit_offset, uint64_t n_bits,
-                 uint32_t n_words) {
+                 uint32_t n_words, uint64_t *replay_map) {
     const dim3 grid((uint32_t)((total + SVS_WG * BPL - 1) / (SVS_WG * BPL)));
     const uint32_t lds_pad = lds_pad_for(env_chunk("SVS_EMBED_WG_PER_CU", embed_wg_per_cu(rows, BPL)), 0);
 #define SVS_CASE(R)                                                                                            \
     case R:                                                                                                    \
         hipLaunchKernelGGL((svs::embed_kernel<R, QM, BPL>), grid, dim3(SVS_WG), lds_pad, st, gray, stego, g, qp, bits, \
-                           bit_offset, n_bits, n_words);                                                       \
+                           bit_offset, n_bits, n_words, replay_map);                                           \
         break;
     if constexpr (BPL == 2) {  // two blocks per lane is only instantiated (and only pays) for one coefficient row
         switch (rows) {
@@ -175,6 +172,37 @@ int launch_embed(int rows, uint64_t total, hipStream_t st, const uint8_t *gray, 
     SVS_HIP(hipGetLastError());
     return SVS_OK;
 }
+
+// second pass of a FAST embed: redo the blocks marked in the replay map with the exact arithmetic (svs_device.hpp)
+int launch_embed_replay(int qm, hipStream_t st, const uint8_t *gray, uint8_t *stego, const svs::Geometry &g,
+                        const svs::QimParams &qp, const uint32_t *bits, uint64_t bit_offset, uint64_t n_bits,
+                        uint32_t n_words, const uint64_t *replay_map, uint64_t map_words, int bpl) {
+    const dim3 grid((uint32_t)((map_words + SVS_WG - 1) / SVS_WG));
+#define SVS_GO(QM)                                                                                                     \
+    hipLaunchKernelGGL((svs::embed_replay_kernel<QM>), grid, dim3(SVS_WG), 0, st, gray, stego, g, qp, bits, bit_offset, \
+                       n_bits, n_words, replay_map, (uint32_t)map_words, (uint32_t)bpl)
+    if (qm == svs::QM_DOUBLE) SVS_GO(svs::QM_DOUBLE);
+    else if (qm == svs::QM_POW2) SVS_GO(svs::QM_POW2);
+    else SVS_GO(svs::QM_F32);
+#undef SVS_GO
+    SVS_HIP(hipGetLastError());
+    return SVS_OK;
+}
+
+// Stream-ordered scratch for the replay map: allocated and released on the caller's stream, so concurrent embeds on
+// different streams never share it and nothing synchronises.
+struct StreamScratch {
+    void *p = nullptr;
+    hipStream_t st = nullptr;
+    int alloc(size_t bytes, hipStream_t stream) {
+        st = stream;
+        SVS_HIP(hipMallocAsync(&p, bytes, st));
+        return SVS_OK;
+    }
+    ~StreamScratch() {
+        if (p) (void)hipFreeAsync(p, st);
+    }
+};
 
 template <int QM, int BPL>
 int launch_extract(int rows, uint64_t total, hipStream_t st, const uint8_t *gray, const svs::Geometry &g,
@@ -268,17 +296,18 @@ struct DevBuf {  // RAII for the host-pointer entry points
 template <int QM, bool EXACT>
 int launch_embed_bgr(int rows, uint64_t total, hipStream_t st, const uint8_t *in, uint8_t *out, uint8_t *ref,
                             const svs::Geometry &g, const svs::ColourParams &c, const svs::QimParams &qp,
-                            const uint32_t *bits, uint64_t bit_offset, uint64_t n_bits, uint32_t n_words) {
+                            const uint32_t *bits, uint64_t bit_offset, uint64_t n_bits, uint32_t n_words,
+                            uint64_t *replay_map) {
     const dim3 grid((uint32_t)((total + SVS_WG - 1) / SVS_WG));
     const uint32_t lds_pad = lds_pad_for(env_chunk("SVS_EMBED_BGR_WG_PER_CU", 0), 16384);
     if constexpr (EXACT) {
         hipLaunchKernelGGL((svs::embed_bgr_kernel<8, QM, true>), grid, dim3(SVS_WG), lds_pad, st, in, out, ref, g, c, qp, bits,
-                           bit_offset, n_bits, n_words);
+                           bit_offset, n_bits, n_words, nullptr);
     } else {
 #define SVS_CASE(R)                                                                                                   \
     case R:                                                                                                           \
         hipLaunchKernelGGL((svs::embed_bgr_kernel<R, QM, false>), grid, dim3(SVS_WG), lds_pad, st, in, out, ref, g, c, qp, bits, \
-                           bit_offset, n_bits, n_words);                                                              \
+                           bit_offset, n_bits, n_words, replay_map);                                                  \
         break;
         switch (rows) {
             SVS_CASE(1) SVS_CASE(2) SVS_CASE(3) SVS_CASE(4) SVS_CASE(5) SVS_CASE(6) SVS_CASE(7) SVS_CASE(8)
@@ -427,7 +456,7 @@ int svs_embed_dev(const uint8_t *d_gray, uint8_t *d_stego, const svs_planes *pla
             if (n_bits == 0) {   // empty payload: the reference's loops break before the first block
                 if (d_gray == d_stego) return SVS_OK;
                 g.n_ac = 1;
-                return launch_embed<svs::QM_F32, 1>(1, total, st, d_gray, d_stego, g, qp, nullptr, 0, 0, 0);
+                return launch_embed<svs::QM_F32, 1>(1, total, st, d_gray, d_stego, g, qp, nullptr, 0, 0, 0, nullptr);
             }
             // delta <= 0 or no coefficients: nothing is consumed, so every block is entered and round-tripped
             g.n_ac = 0;
@@ -443,26 +472,43 @@ int svs_embed_dev(const uint8_t *d_gray, uint8_t *d_stego, const svs_planes *pla
         return SVS_OK;
     }
     if (use == 0) {
-        // pure copy: every block is "past the budget"
+        if (n_bits > 0) {
+            // a non-empty payload of which nothing can be embedded (delta <= 0, no coefficients): the reference still
+            // enters and round-trips every block (config_and_setup.py:143-145,166-169); only the exact arithmetic
+            // reproduces what that does to the pixels, so FAST takes that kernel here
+            g.xcd_chunk = env_chunk("SVS_EMBED_XCD_CHUNK", kEighth);
+            g.n_ac = 0;
+            return launch_embed_exact(svs::QM_F32, total, st, d_gray, d_stego, g, qp, nullptr, 0, 1, 0);
+        }
+        // empty payload: pure copy, every block is "past the budget"
         if (d_gray == d_stego) return SVS_OK;
         g.n_ac = 1;
-        return two ? launch_embed<svs::QM_F32, 2>(1, total, st, d_gray, d_stego, g, qp, nullptr, 0, 0, 0)
-                   : launch_embed<svs::QM_F32, 1>(1, total, st, d_gray, d_stego, g, qp, nullptr, 0, 0, 0);
+        return two ? launch_embed<svs::QM_F32, 2>(1, total, st, d_gray, d_stego, g, qp, nullptr, 0, 0, 0, nullptr)
+                   : launch_embed<svs::QM_F32, 1>(1, total, st, d_gray, d_stego, g, qp, nullptr, 0, 0, 0, nullptr);
     }
     const uint64_t last_byte = (bit_offset + use + 7) / 8;
     const uint64_t words = (last_byte + 3) / 4;
     if (words >= (1ull << 32)) return fail(SVS_ERR_INVALID_ARG, "payload too large for one call");
     const uint32_t *bw = reinterpret_cast<const uint32_t *>(d_bits_packed);
     const int rows = rows_for(n);
+    // replay map: which blocks the fast kernel leaves to the exact arithmetic (svs_device.hpp "REPLAY MAP")
+    const int bpl = two ? 2 : 1;
+    const uint64_t map_words = replay_map_words(total, bpl);
+    StreamScratch map;
+    if (int rc = map.alloc(map_words * sizeof(uint64_t), st)) return rc;
+    uint64_t *d_map = reinterpret_cast<uint64_t *>(map.p);
     int rc;
-#define SVS_GO(QM)                                                                                                   \
-    rc = two ? launch_embed<QM, 2>(rows, total, st, d_gray, d_stego, g, qp, bw, bit_offset, use, (uint32_t)words)   \
-             : launch_embed<QM, 1>(rows, total, st, d_gray, d_stego, g, qp, bw, bit_offset, use, (uint32_t)words)
+#define SVS_GO(QM)                                                                                                          \
+    rc = two ? launch_embed<QM, 2>(rows, total, st, d_gray, d_stego, g, qp, bw, bit_offset, use, (uint32_t)words, d_map)   \
+             : launch_embed<QM, 1>(rows, total, st, d_gray, d_stego, g, qp, bw, bit_offset, use, (uint32_t)words, d_map)
     if (qm == svs::QM_DOUBLE) SVS_GO(svs::QM_DOUBLE);
     else if (qm == svs::QM_POW2) SVS_GO(svs::QM_POW2);
     else SVS_GO(svs::QM_F32);
 #undef SVS_GO
     if (rc) return rc;
+    if (int rc2 = launch_embed_replay(qm, st, d_gray, d_stego, g, qp, bw, bit_offset, use, (uint32_t)words, d_map, map_words,
+                                      bpl))
+        return rc2;
     if (n_embedded) *n_embedded = use;
     return SVS_OK;
 }
@@ -679,7 +725,8 @@ int svs_embed_bgr_dev(const uint8_t *d_bgr_in, int64_t in_row_pitch, int64_t in_
     if (!(delta > 0.0) || n == 0) use = 0;
     if (use > 0 && (!d_bits_packed || ((uintptr_t)d_bits_packed % 4)))
         return fail(SVS_ERR_INVALID_ARG, "bits pointer NULL or not 4-byte aligned");
-    const bool exact = (flags & SVS_EXACT_POCKETFFT) != 0;
+    // nothing embeddable but a non-empty payload: every block is round-tripped, which only the exact arithmetic reproduces
+    const bool exact = (flags & SVS_EXACT_POCKETFFT) != 0 || (use == 0 && n_bits > 0);
     svs::QimParams qp;
     const int qm = make_qim(use == 0 ? 1.0 : delta, &qp);
     g.xcd_chunk = env_chunk("SVS_EMBED_XCD_CHUNK", kEighth);
@@ -698,15 +745,27 @@ int svs_embed_bgr_dev(const uint8_t *d_bgr_in, int64_t in_row_pitch, int64_t in_
         words = (uint32_t)w64;
     }
     const int rows = rows_for((int)g.n_ac);
+    const bool replay = !exact && use > 0;   // FAST with something to embed: second pass over the replay map
+    const uint64_t map_words = replay_map_words(total, 1);
+    StreamScratch map;
+    if (replay)
+        if (int rc = map.alloc(map_words * sizeof(uint64_t), st)) return rc;
+    uint64_t *d_map = reinterpret_cast<uint64_t *>(map.p);
     int rc;
 #define SVS_GO(QM)                                                                                                       \
     rc = exact ? launch_embed_bgr<QM, true>(rows, total, st, d_bgr_in, d_bgr_out, d_gray_ref, g, c, qp, bw, bit_offset,   \
-                                            kernel_bits, words)                                                           \
+                                            kernel_bits, words, nullptr)                                                  \
                : launch_embed_bgr<QM, false>(rows, total, st, d_bgr_in, d_bgr_out, d_gray_ref, g, c, qp, bw, bit_offset,  \
-                                             kernel_bits, words)
-    if (qm == svs::QM_DOUBLE) SVS_GO(svs::QM_DOUBLE);
-    else if (qm == svs::QM_POW2) SVS_GO(svs::QM_POW2);
-    else SVS_GO(svs::QM_F32);
+                                             kernel_bits, words, d_map);                                                  \
+    if (!rc && replay) {                                                                                                 \
+        hipLaunchKernelGGL((svs::embed_bgr_replay_kernel<QM>), dim3((uint32_t)((map_words + SVS_WG - 1) / SVS_WG)),      \
+                           dim3(SVS_WG), 0, st, d_bgr_in, d_bgr_out, g, c, qp, bw, bit_offset, kernel_bits, words, d_map,  \
+                           (uint32_t)map_words);                                                                         \
+        if (hipGetLastError() != hipSuccess) rc = fail(SVS_ERR_HIP, "embed_bgr_replay_kernel launch failed");            \
+    }
+    if (qm == svs::QM_DOUBLE) { SVS_GO(svs::QM_DOUBLE) }
+    else if (qm == svs::QM_POW2) { SVS_GO(svs::QM_POW2) }
+    else { SVS_GO(svs::QM_F32) }
 #undef SVS_GO
     if (rc) return rc;
     if (n_embedded) *n_embedded = use;

@@ -123,50 +123,90 @@ __device__ __forceinline__ void store_rows(uint8_t *dst, int64_t row_pitch, cons
 #ifndef SVS_U2_MIN_WAVES
 #define SVS_U2_MIN_WAVES 6  // register target of the two-row embed kernel (80 VGPRs: +0.4..2.8 % over the default 87)
 #endif
+// `gray` and `stego` may be the same buffer (in-place embedding, include/svsdct.h), so neither is __restrict__: every
+// lane loads its own rows before it stores them and touches nobody else's.
+//
+// REPLAY MAP.  A block whose change is structurally zero (svs::embed_block returns true) must come out of the
+// pocketfft-identical arithmetic instead - 2 000 VALU operations and 140 VGPRs that this kernel cannot afford inline.
+// Such a block is left as it was (not stored), and the wave publishes which of its blocks those are: one 64-bit ballot
+// word per wave and block-of-the-lane, replay_map[(tile * waves_per_workgroup + wave) * BPL + which], bit = lane.
+// Every wave of the grid writes its words (zeros included), so the map needs no clearing.  embed_replay_kernel then
+// redoes exactly those blocks.  On noise-like content the map is all zeros and the second launch is one read of it.
 template <int U, int QM, int BPL, int NFIX = 0>
-__global__ __launch_bounds__(SVS_WG, (U == 2 ? SVS_U2_MIN_WAVES : 1)) void embed_kernel(const uint8_t *__restrict__ gray,
-                                                    uint8_t *__restrict__ stego, const Geometry g,
+__global__ __launch_bounds__(SVS_WG, (U == 2 ? SVS_U2_MIN_WAVES : 1)) void embed_kernel(const uint8_t *gray,
+                                                    uint8_t *stego, const Geometry g,
                                                     const QimParams qp,
                                                     const uint32_t *__restrict__ bits,
                                                     const uint64_t bit_offset, const uint64_t n_bits,
-                                                    const uint32_t n_words) {
-    const uint32_t gblock = (tile_id(g.xcd_chunk) * (uint32_t)SVS_WG + threadIdx.x) * BPL;
-    if (gblock >= g.total_blocks) return;
-    const int64_t off = block_offset(gblock, g);
+                                                    const uint32_t n_words, uint64_t *__restrict__ replay_map) {
+    const uint32_t tile = tile_id(g.xcd_chunk);
+    const uint32_t gblock = (tile * (uint32_t)SVS_WG + threadIdx.x) * BPL;
+    bool replay_a = false, replay_b = false;
+    if (gblock < g.total_blocks) {
+        const int64_t off = block_offset(gblock, g);
+        typename RowVec<BPL>::type v[8];
+        load_rows<BPL>(gray + off, g.row_pitch, v);
 
-    typename RowVec<BPL>::type v[8];
-    load_rows<BPL>(gray + off, g.row_pitch, v);
+        const uint32_t n = g.n_ac;
+        const uint64_t first = (uint64_t)gblock * n;  // stream index of this lane's first bit
+        if (first >= n_bits) {
+            // past the budget: byte-identical copy (the reference's loops `break`, :130,:132)
+            if (stego != gray) store_rows<BPL>(stego + off, g.row_pitch, v);
+        } else {
+            uint32_t ax[8], ay[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) { ax[r] = v[r].x; ay[r] = v[r].y; }
+            {
+                uint32_t hi, lo;
+                payload_window(bits, n_words, bit_offset + first, hi, lo);
+                replay_a = embed_block<U, QM, NFIX>(ax, ay, n, block_budget(first, n_bits, n), hi, lo, qp);
+            }
+#pragma unroll
+            for (int r = 0; r < 8; ++r) { v[r].x = ax[r]; v[r].y = ay[r]; }
+            if constexpr (BPL == 2) {
+                uint32_t bx[8], by[8];
+#pragma unroll
+                for (int r = 0; r < 8; ++r) { bx[r] = v[r].z; by[r] = v[r].w; }
+                // a budget of 0 (only the lane the payload ends in can see it here) yields an all-zero
+                // change, i.e. block B is stored back unchanged - no branch needed
+                uint32_t hi, lo;
+                payload_window(bits, n_words, bit_offset + first + n, hi, lo);
+                replay_b = embed_block<U, QM, NFIX>(bx, by, n, block_budget(first + n, n_bits, n), hi, lo, qp);
+#pragma unroll
+                for (int r = 0; r < 8; ++r) { v[r].z = bx[r]; v[r].w = by[r]; }
+            }
+            if (!(replay_a | replay_b)) {
+                store_rows<BPL>(stego + off, g.row_pitch, v);
+            } else if constexpr (BPL == 2) {  // rare: store only the block that keeps its fast result
+                typename RowVec<1>::type h[8];
+                if (!replay_a) {
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) { h[r].x = v[r].x; h[r].y = v[r].y; }
+                    store_rows<1>(stego + off, g.row_pitch, h);
+                }
+                if (!replay_b) {
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) { h[r].x = v[r].z; h[r].y = v[r].w; }
+                    store_rows<1>(stego + off + 8, g.row_pitch, h);
+                }
+            }
+        }
+    }
+    if (replay_map != nullptr) {  // kernel argument: uniform
+        const uint64_t ma = __ballot(replay_a);
+        uint64_t *slot = replay_map + ((uint64_t)tile * (SVS_WG / 64) + (threadIdx.x >> 6)) * BPL;
+        if constexpr (BPL == 2) {
+            const uint64_t mb = __ballot(replay_b);
+            if ((threadIdx.x & 63u) == 0) { slot[0] = ma; slot[1] = mb; }
+        } else {
+            if ((threadIdx.x & 63u) == 0) slot[0] = ma;
+        }
+    }
+}
 
-    const uint32_t n = g.n_ac;
-    const uint64_t first = (uint64_t)gblock * n;  // stream index of this lane's first bit
-    if (first >= n_bits) {
-        // past the budget: byte-identical copy (the reference's loops `break`, :130,:132)
-        if (stego != gray) store_rows<BPL>(stego + off, g.row_pitch, v);
-        return;
-    }
-    uint32_t ax[8], ay[8];
-#pragma unroll
-    for (int r = 0; r < 8; ++r) { ax[r] = v[r].x; ay[r] = v[r].y; }
-    {
-        uint32_t hi, lo;
-        payload_window(bits, n_words, bit_offset + first, hi, lo);
-        embed_block<U, QM, NFIX>(ax, ay, n, block_budget(first, n_bits, n), hi, lo, qp);
-    }
-#pragma unroll
-    for (int r = 0; r < 8; ++r) { v[r].x = ax[r]; v[r].y = ay[r]; }
-    if constexpr (BPL == 2) {
-        uint32_t bx[8], by[8];
-#pragma unroll
-        for (int r = 0; r < 8; ++r) { bx[r] = v[r].z; by[r] = v[r].w; }
-        // a budget of 0 (only the lane the payload ends in can see it here) yields an all-zero
-        // change, i.e. block B is stored back unchanged - no branch needed
-        uint32_t hi, lo;
-        payload_window(bits, n_words, bit_offset + first + n, hi, lo);
-        embed_block<U, QM, NFIX>(bx, by, n, block_budget(first + n, n_bits, n), hi, lo, qp);
-#pragma unroll
-        for (int r = 0; r < 8; ++r) { v[r].z = bx[r]; v[r].w = by[r]; }
-    }
-    store_rows<BPL>(stego + off, g.row_pitch, v);
+// global block a bit of the replay map stands for (the inverse of the indexing in embed_kernel)
+__device__ __forceinline__ uint32_t replay_block(uint32_t word, uint32_t bit, uint32_t bpl) {
+    return bpl == 1 ? 64u * word + bit : (word >> 1) * 128u + 2u * bit + (word & 1u);
 }
 
 // Tail of the extract kernels: a wavefront's 64*BPL consecutive blocks produce exactly n*BPL aligned
@@ -232,17 +272,42 @@ __global__ __launch_bounds__(SVS_WG) void extract_kernel(const uint8_t *__restri
     // each block's bits, MSB first: bit i at position 63-i of hi:lo
     uint32_t hi_a = 0, lo_a = 0, hi_b = 0, lo_b = 0;
     if (gblock < g.total_blocks) {
-        typename RowVec<BPL>::type v[8];
-        load_rows<BPL>(gray + block_offset(gblock, g), g.row_pitch, v);
-        uint32_t ax[8], ay[8];
+        const uint8_t *src = gray + block_offset(gblock, g);
+        bool tie_a, tie_b = false;
+        {
+            typename RowVec<BPL>::type v[8];
+            load_rows<BPL>(src, g.row_pitch, v);
+            uint32_t ax[8], ay[8];
 #pragma unroll
-        for (int r = 0; r < 8; ++r) { ax[r] = v[r].x; ay[r] = v[r].y; }
-        extract_block<U, QM, NFIX>(ax, ay, n, qp, hi_a, lo_a);
+            for (int r = 0; r < 8; ++r) { ax[r] = v[r].x; ay[r] = v[r].y; }
+            tie_a = extract_block<U, QM, NFIX>(ax, ay, n, qp, hi_a, lo_a);
+            if constexpr (BPL == 2) {
+                uint32_t bx[8], by[8];
+#pragma unroll
+                for (int r = 0; r < 8; ++r) { bx[r] = v[r].z; by[r] = v[r].w; }
+                tie_b = extract_block<U, QM, NFIX>(bx, by, n, qp, hi_b, lo_b);
+            }
+        }
+        // A quantiser input within the forward error bound of a rounding tie (svs_block.hpp, SVS_TIE_SLOPE): redo the
+        // block with the pocketfft-identical transform.  Waves without such a lane branch over this (execz); the rows
+        // are fetched again rather than kept alive in 16 registers.  Never taken on stego frames at delta >= 8.
+        if (tie_a) {
+            typename RowVec<1>::type v[8];
+            load_rows<1>(src, g.row_pitch, v);
+            uint32_t ax[8], ay[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) { ax[r] = v[r].x; ay[r] = v[r].y; }
+            extract_block_exact<U, QM>(ax, ay, n, qp, hi_a, lo_a);
+        }
         if constexpr (BPL == 2) {
-            uint32_t bx[8], by[8];
+            if (tie_b) {
+                typename RowVec<1>::type v[8];
+                load_rows<1>(src + 8, g.row_pitch, v);
+                uint32_t bx[8], by[8];
 #pragma unroll
-            for (int r = 0; r < 8; ++r) { bx[r] = v[r].z; by[r] = v[r].w; }
-            extract_block<U, QM, NFIX>(bx, by, n, qp, hi_b, lo_b);
+                for (int r = 0; r < 8; ++r) { bx[r] = v[r].x; by[r] = v[r].y; }
+                extract_block_exact<U, QM>(bx, by, n, qp, hi_b, lo_b);
+            }
         }
     }
 
@@ -340,8 +405,8 @@ __global__ __launch_bounds__(SVS_WG) void extract_shuffle_kernel(const uint8_t *
 #define SVS_EXACT_MIN_WAVES 2  // waves per SIMD the exact embed kernel is register-allocated for (2: +1..3 % over 3; 4 spills 52 B and is 8 % slower)
 #endif
 template <int QM, int U = 8>  // U: coefficient rows the quantiser loop covers (flat indices 1..n lie in rows < U)
-__global__ __launch_bounds__(SVS_WG, SVS_EXACT_MIN_WAVES) void embed_exact_kernel(const uint8_t *__restrict__ gray,
-                                                          uint8_t *__restrict__ stego, const Geometry g,
+__global__ __launch_bounds__(SVS_WG, SVS_EXACT_MIN_WAVES) void embed_exact_kernel(const uint8_t *gray,  // may alias stego
+                                                          uint8_t *stego, const Geometry g,
                                                           const QimParams qp,
                                                           const uint32_t *__restrict__ bits,
                                                           const uint64_t bit_offset, const uint64_t n_bits,
@@ -366,6 +431,40 @@ __global__ __launch_bounds__(SVS_WG, SVS_EXACT_MIN_WAVES) void embed_exact_kerne
 #pragma unroll
     for (int r = 0; r < 8; ++r) { v[r].x = ax[r]; v[r].y = ay[r]; }
     store_rows<1>(stego + off, g.row_pitch, v);
+}
+
+// Second pass of FAST embedding: the blocks embed_kernel marked in the replay map are redone with the exact arithmetic,
+// read from `gray` (embed_kernel left them untouched, also when embedding in place) and written to `stego`.  One lane per
+// map word; a lane walks the set bits of its word.  With an all-zero map this is a read of total_blocks / 8 bytes.
+template <int QM>
+__global__ __launch_bounds__(SVS_WG, SVS_EXACT_MIN_WAVES) void embed_replay_kernel(const uint8_t *gray, uint8_t *stego,
+                                                          const Geometry g, const QimParams qp,
+                                                          const uint32_t *__restrict__ bits, const uint64_t bit_offset,
+                                                          const uint64_t n_bits, const uint32_t n_words,
+                                                          const uint64_t *__restrict__ replay_map,
+                                                          const uint32_t map_words, const uint32_t bpl) {
+    const uint32_t word = blockIdx.x * (uint32_t)SVS_WG + threadIdx.x;
+    if (word >= map_words) return;
+    uint64_t todo = replay_map[word];
+    const uint32_t n = g.n_ac;
+    while (todo != 0) {
+        const uint32_t bit = (uint32_t)__builtin_ctzll(todo);
+        todo &= todo - 1;
+        const uint32_t gblock = replay_block(word, bit, bpl);
+        const int64_t off = block_offset(gblock, g);
+        typename RowVec<1>::type v[8];
+        load_rows<1>(gray + off, g.row_pitch, v);
+        uint32_t ax[8], ay[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) { ax[r] = v[r].x; ay[r] = v[r].y; }
+        const uint64_t first = (uint64_t)gblock * n;
+        uint32_t hi, lo;
+        payload_window(bits, n_words, bit_offset + first, hi, lo);
+        embed_block_exact<8, QM>(ax, ay, n, block_budget(first, n_bits, n), hi, lo, qp);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) { v[r].x = ax[r]; v[r].y = ay[r]; }
+        store_rows<1>(stego + off, g.row_pitch, v);
+    }
 }
 
 template <int U, int QM>
@@ -603,7 +702,7 @@ __device__ __forceinline__ void wave_load_gray(const uint8_t *__restrict__ bgr, 
 }
 
 // Same, HALF rows at a time (two rounds of 4 rows): half the registers in flight, for kernels that are short of them
-__device__ __forceinline__ void wave_load_gray_halves(const uint8_t *__restrict__ bgr, const Geometry &g,
+__device__ __forceinline__ void wave_load_gray_halves(const uint8_t *bgr, const Geometry &g,
                                                       const ColourParams &c, uint32_t wave_first, uint32_t lane,
                                                       u32x2 *rowbuf, uint32_t (&ax)[8], uint32_t (&ay)[8]) {
 #pragma unroll 1
@@ -637,10 +736,11 @@ __device__ __forceinline__ void wave_load_gray_halves(const uint8_t *__restrict_
 
 // Gray rows of a wave's 64 blocks -> interleaved BGR with B = G = R, through the wave-private tile `mine` (8 rows x 64
 // lanes of 8 gray bytes): every store instruction covers 512 contiguous bytes.
+// `skip`: wave mask of blocks (bit = lane) whose output is NOT written (left to the replay pass)
 __device__ __forceinline__ void wave_store_gray_as_bgr(u32x2 *mine, uint32_t lane, uint32_t gblock, bool live,
                                                        const uint32_t (&ax)[8], const uint32_t (&ay)[8],
-                                                       uint8_t *__restrict__ bgr_out, const Geometry &g,
-                                                       const ColourParams &c) {
+                                                       uint8_t *bgr_out, const Geometry &g,
+                                                       const ColourParams &c, uint64_t skip = 0) {
     if (live) {
 #pragma unroll
         for (int r = 0; r < 8; ++r) { u32x2 v; v.x = ax[r]; v.y = ay[r]; mine[r * 64 + lane] = v; }
@@ -651,7 +751,7 @@ __device__ __forceinline__ void wave_store_gray_as_bgr(u32x2 *mine, uint32_t lan
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
         const uint32_t owner = wu.owner[j], part = wu.part[j];
-        if (!wu.live[j]) continue;
+        if (!wu.live[j] || ((skip >> owner) & 1ull)) continue;
         // gray pixels feeding the unit's two dwords (v_perm_b32: selector bytes 0-3 pick from the low gray dword,
         // 4-7 from the high one): part 0 = p0 p0 p0 p1 | p1 p1 p2 p2, part 1 = p2 p3 p3 p3 | p4 p4 p4 p5,
         // part 2 = p5 p5 p6 p6 | p6 p7 p7 p7
@@ -707,24 +807,24 @@ __global__ __launch_bounds__(SVS_WG) void gray_to_bgr_kernel(const uint8_t *__re
 // 24-byte row of the wave's block u/3 - so every store instruction covers 512 contiguous bytes instead of 8 bytes in
 // every 24.
 template <int U, int QM, bool EXACT>
-__global__ __launch_bounds__(SVS_WG) void embed_bgr_kernel(const uint8_t *__restrict__ bgr_in,
-                                                        uint8_t *__restrict__ bgr_out, uint8_t *__restrict__ gray_ref,
+__global__ __launch_bounds__(SVS_WG) void embed_bgr_kernel(const uint8_t *bgr_in,   // may alias bgr_out
+                                                        uint8_t *bgr_out, uint8_t *__restrict__ gray_ref,
                                                         const Geometry g, const ColourParams c, const QimParams qp,
                                                         const uint32_t *__restrict__ bits, const uint64_t bit_offset,
-                                                        const uint64_t n_bits, const uint32_t n_words) {
+                                                        const uint64_t n_bits, const uint32_t n_words,
+                                                        uint64_t *__restrict__ replay_map) {
 #if !defined(SVS_BGR_DIRECT_STORE)
-    __shared__ __attribute__((aligned(16))) u32x2 tile[SVS_WG / 64][8][64];
+    __shared__ __attribute__((aligned(16))) u32x2 lds_tile[SVS_WG / 64][8][64];
 #endif
-    const uint32_t gblock = tile_id(g.xcd_chunk) * (uint32_t)SVS_WG + threadIdx.x;
+    const uint32_t tile = tile_id(g.xcd_chunk);
+    const uint32_t gblock = tile * (uint32_t)SVS_WG + threadIdx.x;
     const bool live = gblock < g.total_blocks;
-#if defined(SVS_BGR_DIRECT_STORE)
-    if (!live) return;
-#endif
+    bool replay = false;  // FAST only: structurally zero change -> embed_bgr_replay_kernel redoes the block (see embed_kernel)
     uint32_t ax[8], ay[8];
 #if !defined(SVS_BGR_DIRECT_LOAD) && !defined(SVS_BGR_DIRECT_STORE)
     // cooperative load, four rows at a time: +5..7 % over per-lane loads at a 24-byte stride in FAST mode (62 -> 78 VGPRs),
     // neutral in EXACT mode; all eight rows at once cost 100+ VGPRs and gained 1 % (profiles/r01_aux_kernel_rates.txt)
-    wave_load_gray_halves(bgr_in, g, c, gblock - (threadIdx.x & 63u), threadIdx.x & 63u, &tile[threadIdx.x >> 6][0][0], ax, ay);
+    wave_load_gray_halves(bgr_in, g, c, gblock - (threadIdx.x & 63u), threadIdx.x & 63u, &lds_tile[threadIdx.x >> 6][0][0], ax, ay);
 #else
     if (live) {
         const uint8_t *src = bgr_in + block_offset_bgr(gblock, g, c.in_row_pitch, c.in_frame_pitch);
@@ -751,20 +851,66 @@ __global__ __launch_bounds__(SVS_WG) void embed_bgr_kernel(const uint8_t *__rest
             uint32_t hi, lo;
             payload_window(bits, n_words, bit_offset + first, hi, lo);
             if constexpr (EXACT) embed_block_exact<8, QM>(ax, ay, n, block_budget(first, n_bits, n), hi, lo, qp);
-            else embed_block<U, QM>(ax, ay, n, block_budget(first, n_bits, n), hi, lo, qp);
+            else replay = embed_block<U, QM>(ax, ay, n, block_budget(first, n_bits, n), hi, lo, qp);
         }
     }
+    const uint64_t skip = EXACT ? 0ull : __ballot(replay);
+    if constexpr (!EXACT) {
+        if (replay_map != nullptr && (threadIdx.x & 63u) == 0)
+            replay_map[(uint64_t)tile * (SVS_WG / 64) + (threadIdx.x >> 6)] = skip;
+    }
 #if defined(SVS_BGR_DIRECT_STORE)
-    uint8_t *dst = bgr_out + block_offset_bgr(gblock, g, c.out_row_pitch, c.out_frame_pitch);
+    if (live && !replay) {
+        uint8_t *dst = bgr_out + block_offset_bgr(gblock, g, c.out_row_pitch, c.out_frame_pitch);
 #pragma unroll
-    for (int r = 0; r < 8; ++r) {
-        u32x2 q0, q1, q2;
-        gray8_to_bgr(ax[r], ay[r], q0, q1, q2);
-        store_bgr_row(dst + r * c.out_row_pitch, q0, q1, q2);
+        for (int r = 0; r < 8; ++r) {
+            u32x2 q0, q1, q2;
+            gray8_to_bgr(ax[r], ay[r], q0, q1, q2);
+            store_bgr_row(dst + r * c.out_row_pitch, q0, q1, q2);
+        }
     }
 #else
-    wave_store_gray_as_bgr(&tile[threadIdx.x >> 6][0][0], threadIdx.x & 63u, gblock, live, ax, ay, bgr_out, g, c);
+    wave_store_gray_as_bgr(&lds_tile[threadIdx.x >> 6][0][0], threadIdx.x & 63u, gblock, live, ax, ay, bgr_out, g, c, skip);
 #endif
+}
+
+// Second pass of the FAST fused colour embed: blocks marked in the replay map are redone from the original BGR pixels
+// with the exact arithmetic (gray reference frame: already written by the first pass).  One lane per map word.
+template <int QM>
+__global__ __launch_bounds__(SVS_WG, SVS_EXACT_MIN_WAVES) void embed_bgr_replay_kernel(const uint8_t *bgr_in, uint8_t *bgr_out,
+                                                          const Geometry g, const ColourParams c, const QimParams qp,
+                                                          const uint32_t *__restrict__ bits, const uint64_t bit_offset,
+                                                          const uint64_t n_bits, const uint32_t n_words,
+                                                          const uint64_t *__restrict__ replay_map,
+                                                          const uint32_t map_words) {
+    const uint32_t word = blockIdx.x * (uint32_t)SVS_WG + threadIdx.x;
+    if (word >= map_words) return;
+    uint64_t todo = replay_map[word];
+    const uint32_t n = g.n_ac;
+    while (todo != 0) {
+        const uint32_t bit = (uint32_t)__builtin_ctzll(todo);
+        todo &= todo - 1;
+        const uint32_t gblock = replay_block(word, bit, 1u);
+        const uint8_t *src = bgr_in + block_offset_bgr(gblock, g, c.in_row_pitch, c.in_frame_pitch);
+        uint32_t ax[8], ay[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            u32x2 q0, q1, q2;
+            load_bgr_row(src + r * c.in_row_pitch, q0, q1, q2);
+            bgr8_to_gray(q0, q1, q2, c, ax[r], ay[r]);
+        }
+        const uint64_t first = (uint64_t)gblock * n;
+        uint32_t hi, lo;
+        payload_window(bits, n_words, bit_offset + first, hi, lo);
+        embed_block_exact<8, QM>(ax, ay, n, block_budget(first, n_bits, n), hi, lo, qp);
+        uint8_t *dst = bgr_out + block_offset_bgr(gblock, g, c.out_row_pitch, c.out_frame_pitch);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            u32x2 q0, q1, q2;
+            gray8_to_bgr(ax[r], ay[r], q0, q1, q2);
+            store_bgr_row(dst + r * c.out_row_pitch, q0, q1, q2);
+        }
+    }
 }
 
 // extract straight from interleaved BGR frames (gray computed on the fly; pocketfft-identical forward)

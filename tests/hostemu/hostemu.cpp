@@ -13,15 +13,7 @@
 
 namespace {
 
-// same mode selection as make_qim() in csrc/svs_capi.hip
-int make_qim(double delta, svs::QimParams *qp) {
-    qp->delta_f = (float)delta;
-    qp->inv_delta_f = 1.0f / qp->delta_f;
-    qp->delta_d = delta;
-    if ((double)qp->delta_f != delta) return svs::QM_DOUBLE;
-    int e = 0;
-    return std::frexp(delta, &e) == 0.5 ? svs::QM_POW2 : svs::QM_F32;
-}
+using svs::make_qim;   // the host-side parameter set-up the library itself uses
 
 struct Blk {
     uint32_t x[8], y[8];
@@ -40,45 +32,54 @@ struct Blk {
 };
 
 template <int U>
-void embed_u(Blk &raw, uint32_t n, uint32_t nb, uint32_t hi, uint32_t lo, const svs::QimParams &qp, int qm) {
-    if (qm == svs::QM_DOUBLE) svs::embed_block<U, svs::QM_DOUBLE>(raw.x, raw.y, n, nb, hi, lo, qp);
-    else if (qm == svs::QM_POW2) svs::embed_block<U, svs::QM_POW2>(raw.x, raw.y, n, nb, hi, lo, qp);
-    else svs::embed_block<U, svs::QM_F32>(raw.x, raw.y, n, nb, hi, lo, qp);
+bool embed_u(Blk &raw, uint32_t n, uint32_t nb, uint32_t hi, uint32_t lo, const svs::QimParams &qp, int qm) {
+    if (qm == svs::QM_DOUBLE) return svs::embed_block<U, svs::QM_DOUBLE>(raw.x, raw.y, n, nb, hi, lo, qp);
+    if (qm == svs::QM_POW2) return svs::embed_block<U, svs::QM_POW2>(raw.x, raw.y, n, nb, hi, lo, qp);
+    return svs::embed_block<U, svs::QM_F32>(raw.x, raw.y, n, nb, hi, lo, qp);
 }
 
-template <int U, int NFIX>
-void embed_fixed(Blk &raw, uint32_t nb, uint32_t hi, uint32_t lo, const svs::QimParams &qp, int qm) {
-    if (qm == svs::QM_DOUBLE) svs::embed_block<U, svs::QM_DOUBLE, NFIX>(raw.x, raw.y, NFIX, nb, hi, lo, qp);
-    else if (qm == svs::QM_POW2) svs::embed_block<U, svs::QM_POW2, NFIX>(raw.x, raw.y, NFIX, nb, hi, lo, qp);
-    else svs::embed_block<U, svs::QM_F32, NFIX>(raw.x, raw.y, NFIX, nb, hi, lo, qp);
-}
-
-void embed_dispatch(int rows, Blk &raw, uint32_t n, uint32_t nb, uint32_t hi, uint32_t lo,
+// -> true: the block is to be replayed with the exact arithmetic (svs::embed_block's return value)
+bool embed_dispatch(int rows, Blk &raw, uint32_t n, uint32_t nb, uint32_t hi, uint32_t lo,
                     const svs::QimParams &qp, int dbl) {
     switch (rows) {
-        case 1: embed_u<1>(raw, n, nb, hi, lo, qp, dbl); break;
-        case 2: embed_u<2>(raw, n, nb, hi, lo, qp, dbl); break;
-        case 3: embed_u<3>(raw, n, nb, hi, lo, qp, dbl); break;
-        case 4: embed_u<4>(raw, n, nb, hi, lo, qp, dbl); break;
-        case 5: embed_u<5>(raw, n, nb, hi, lo, qp, dbl); break;
-        case 6: embed_u<6>(raw, n, nb, hi, lo, qp, dbl); break;
-        case 7: embed_u<7>(raw, n, nb, hi, lo, qp, dbl); break;
-        default: embed_u<8>(raw, n, nb, hi, lo, qp, dbl); break;
+        case 1: return embed_u<1>(raw, n, nb, hi, lo, qp, dbl);
+        case 2: return embed_u<2>(raw, n, nb, hi, lo, qp, dbl);
+        case 3: return embed_u<3>(raw, n, nb, hi, lo, qp, dbl);
+        case 4: return embed_u<4>(raw, n, nb, hi, lo, qp, dbl);
+        case 5: return embed_u<5>(raw, n, nb, hi, lo, qp, dbl);
+        case 6: return embed_u<6>(raw, n, nb, hi, lo, qp, dbl);
+        case 7: return embed_u<7>(raw, n, nb, hi, lo, qp, dbl);
+        default: return embed_u<8>(raw, n, nb, hi, lo, qp, dbl);
+    }
+}
+
+void embed_exact_dispatch(Blk &raw, uint32_t n, uint32_t nb, uint32_t hi, uint32_t lo, const svs::QimParams &qp, int qm) {
+    if (qm == svs::QM_DOUBLE) svs::embed_block_exact<8, svs::QM_DOUBLE>(raw.x, raw.y, n, nb, hi, lo, qp);
+    else if (qm == svs::QM_POW2) svs::embed_block_exact<8, svs::QM_POW2>(raw.x, raw.y, n, nb, hi, lo, qp);
+    else svs::embed_block_exact<8, svs::QM_F32>(raw.x, raw.y, n, nb, hi, lo, qp);
+}
+
+// -> true: some quantiser input is within the forward error bound of a tie (svs::extract_block's return value)
+template <int QM>
+bool extract_dispatch(int rows, const Blk &raw, uint32_t n, const svs::QimParams &d, uint32_t &hi, uint32_t &lo) {
+    if (n == 10) return svs::extract_block<2, QM, 10>(raw.x, raw.y, n, d, hi, lo);   // as csrc/svs_capi.hip
+    switch (rows) {
+        case 1: return svs::extract_block<1, QM>(raw.x, raw.y, n, d, hi, lo);
+        case 2: return svs::extract_block<2, QM>(raw.x, raw.y, n, d, hi, lo);
+        case 3: return svs::extract_block<3, QM>(raw.x, raw.y, n, d, hi, lo);
+        case 4: return svs::extract_block<4, QM>(raw.x, raw.y, n, d, hi, lo);
+        case 5: return svs::extract_block<5, QM>(raw.x, raw.y, n, d, hi, lo);
+        case 6: return svs::extract_block<6, QM>(raw.x, raw.y, n, d, hi, lo);
+        case 7: return svs::extract_block<7, QM>(raw.x, raw.y, n, d, hi, lo);
+        default: return svs::extract_block<8, QM>(raw.x, raw.y, n, d, hi, lo);
     }
 }
 
 template <int QM>
-void extract_dispatch(int rows, const Blk &raw, uint32_t n, const svs::QimParams &d, uint32_t &hi, uint32_t &lo) {
-    if (n == 10) return svs::extract_block<2, QM, 10>(raw.x, raw.y, n, d, hi, lo);   // as csrc/svs_capi.hip
-    switch (rows) {
-        case 1: svs::extract_block<1, QM>(raw.x, raw.y, n, d, hi, lo); break;
-        case 2: svs::extract_block<2, QM>(raw.x, raw.y, n, d, hi, lo); break;
-        case 3: svs::extract_block<3, QM>(raw.x, raw.y, n, d, hi, lo); break;
-        case 4: svs::extract_block<4, QM>(raw.x, raw.y, n, d, hi, lo); break;
-        case 5: svs::extract_block<5, QM>(raw.x, raw.y, n, d, hi, lo); break;
-        case 6: svs::extract_block<6, QM>(raw.x, raw.y, n, d, hi, lo); break;
-        case 7: svs::extract_block<7, QM>(raw.x, raw.y, n, d, hi, lo); break;
-        default: svs::extract_block<8, QM>(raw.x, raw.y, n, d, hi, lo); break;
+void extract_fast(int rows, const Blk &raw, uint32_t n, const svs::QimParams &d, uint32_t &hi, uint32_t &lo, uint64_t *redone) {
+    if (extract_dispatch<QM>(rows, raw, n, d, hi, lo)) {   // near a tie: the kernels redo the block exactly
+        svs::extract_block_exact<8, QM>(raw.x, raw.y, n, d, hi, lo);
+        if (redone) ++*redone;
     }
 }
 
@@ -88,7 +89,9 @@ extern "C" {
 
 // frames: contiguous [F][H][W]; bits: packed MSB-first, padded by the caller to a multiple of 4 bytes
 uint64_t emu_embed(const uint8_t *gray, uint8_t *stego, int F, int H, int W, double delta, int n_ac,
-                   const uint8_t *bits, uint64_t bits_bytes, uint64_t bit_offset, uint64_t n_bits, int exact) {
+                   const uint8_t *bits, uint64_t bits_bytes, uint64_t bit_offset, uint64_t n_bits, int exact,
+                   uint64_t *n_replayed) {
+    if (n_replayed) *n_replayed = 0;
     const int n = n_ac < 0 ? 0 : (n_ac > 63 ? 63 : n_ac);
     const uint64_t bpf = (uint64_t)(H / 8) * (W / 8), total = bpf * F;
     std::memcpy(stego, gray, (size_t)F * H * W);
@@ -97,7 +100,7 @@ uint64_t emu_embed(const uint8_t *gray, uint8_t *stego, int F, int H, int W, dou
     svs::QimParams qp;
     const int dbl = make_qim(use ? delta : 1.0, &qp);
     if (use == 0) {
-        if (exact && n_bits > 0) {  // nothing consumed -> every block entered and round-tripped
+        if (n_bits > 0) {  // nothing consumed -> every block entered and round-tripped (either mode: svs_embed_dev)
             for (uint64_t gb = 0; gb < total; ++gb) {
                 const uint64_t f = gb / bpf, b = gb % bpf;
                 uint8_t *p = stego + f * (uint64_t)H * W + (b / (W / 8)) * 8 * W + (b % (W / 8)) * 8;
@@ -121,17 +124,26 @@ uint64_t emu_embed(const uint8_t *gray, uint8_t *stego, int F, int H, int W, dou
         raw.load(p, (size_t)W);
         uint32_t hi, lo;
         svs::payload_window(reinterpret_cast<const uint32_t *>(bits), n_words, bit_offset + first, hi, lo);
-        if (!exact) embed_dispatch(svs::rows_for(n), raw, (uint32_t)n, nb, hi, lo, qp, dbl);
-        else if (dbl == svs::QM_DOUBLE) svs::embed_block_exact<8, svs::QM_DOUBLE>(raw.x, raw.y, (uint32_t)n, nb, hi, lo, qp);
-        else if (dbl == svs::QM_POW2) svs::embed_block_exact<8, svs::QM_POW2>(raw.x, raw.y, (uint32_t)n, nb, hi, lo, qp);
-        else svs::embed_block_exact<8, svs::QM_F32>(raw.x, raw.y, (uint32_t)n, nb, hi, lo, qp);
+        if (!exact) {
+            // FAST: blocks whose change is structurally zero are replayed with the exact arithmetic (the kernels do that in
+            // a second pass over a per-block bitmap; csrc/svs_device.hpp "replay")
+            if (embed_dispatch(svs::rows_for(n), raw, (uint32_t)n, nb, hi, lo, qp, dbl)) {
+                raw.load(p, (size_t)W);
+                embed_exact_dispatch(raw, (uint32_t)n, nb, hi, lo, qp, dbl);
+                if (n_replayed) ++*n_replayed;
+            }
+        } else {
+            embed_exact_dispatch(raw, (uint32_t)n, nb, hi, lo, qp, dbl);
+        }
         raw.store(p, (size_t)W);
     }
     return use;
 }
 
 // out_flags: one byte (0/1) per extracted bit, F*(H/8)*(W/8)*n entries
-uint64_t emu_extract(const uint8_t *gray, int F, int H, int W, double delta, int n_ac, uint8_t *out_flags, int exact) {
+uint64_t emu_extract(const uint8_t *gray, int F, int H, int W, double delta, int n_ac, uint8_t *out_flags, int exact,
+                     uint64_t *n_redone) {
+    if (n_redone) *n_redone = 0;
     const int n = n_ac < 0 ? 0 : (n_ac > 63 ? 63 : n_ac);
     const uint64_t bpf = (uint64_t)(H / 8) * (W / 8), total = bpf * F;
     if (n == 0) return 0;
@@ -151,8 +163,8 @@ uint64_t emu_extract(const uint8_t *gray, int F, int H, int W, double delta, int
         if (exact || svs::rows_for(n) == 1) {   // one coefficient row: both modes use the pocketfft-identical forward
             if (qm == svs::QM_POW2) svs::extract_block_exact<8, svs::QM_POW2>(raw.x, raw.y, (uint32_t)n, qp, hi, lo);
             else svs::extract_block_exact<8, svs::QM_F32>(raw.x, raw.y, (uint32_t)n, qp, hi, lo);
-        } else if (qm == svs::QM_POW2) extract_dispatch<svs::QM_POW2>(svs::rows_for(n), raw, (uint32_t)n, qp, hi, lo);
-        else extract_dispatch<svs::QM_F32>(svs::rows_for(n), raw, (uint32_t)n, qp, hi, lo);
+        } else if (qm == svs::QM_POW2) extract_fast<svs::QM_POW2>(svs::rows_for(n), raw, (uint32_t)n, qp, hi, lo, n_redone);
+        else extract_fast<svs::QM_F32>(svs::rows_for(n), raw, (uint32_t)n, qp, hi, lo, n_redone);
         for (int i = 0; i < n; ++i) out_flags[gb * n + i] = (uint8_t)svs::window_bit(hi, lo, i);
     }
     return total * n;

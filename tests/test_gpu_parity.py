@@ -13,8 +13,8 @@ import os
 import numpy as np
 import pytest
 
-from testlib import (NOISE_ONLY_CASES, REPO, case_inputs, emu_embed, emu_extract, exact_tie_mask, golden_bits,
-                     near_tie_mask, sha, single_frame_cases)
+from testlib import (CONTRACT_POINTS, REPO, case_inputs, emu_embed, emu_extract, exact_tie_mask, golden_bits,
+                     natural_like, sha, single_frame_cases, structured_covers)
 from oracle import qim_dct_oracle as orc
 from svsdct import batch, native, synth
 from svsdct.native import Planes
@@ -78,18 +78,7 @@ def test_exact_mode_full_size_equals_oracle(shape, n_ac, delta, frames):
     assert np.array_equal(np.unpackbits(packed, count=n_bits), orc.batch_extract_bits(cover, delta, n_ac))
 
 
-def _natural_like(h, w, seed):
-    """Frames with what real video has and uniform noise lacks: flat black bars, saturated highlights, smooth
-    gradients, low-amplitude texture - the content on which the reference's round-trip artefacts and
-    clipping show up."""
-    rng = np.random.default_rng(seed)
-    yy, xx = np.mgrid[0:h, 0:w]
-    img = 128 + 90 * np.sin(xx / 97.0) * np.cos(yy / 61.0) + rng.normal(0, 2.0, (h, w))
-    img[: h // 8] = 0                      # letterbox
-    img[-h // 8:] = 16
-    img[h // 3: h // 2, w // 4: w // 2] = 255          # blown-out highlight
-    img[h // 2: h // 2 + 64, : w // 3] = 128            # flat mid-gray panel
-    return np.clip(np.rint(img), 0, 255).astype(np.uint8)
+_natural_like = natural_like
 
 
 @pytest.mark.parametrize("n_ac,delta", [(3, 8), (10, 20), (7, 4)])
@@ -107,13 +96,59 @@ def test_exact_mode_on_natural_like_content(n_ac, delta):
     assert (want[0, 1080 // 2: 1080 // 2 + 64, : 1920 // 3 - 8] != flat).any() or delta == 4
     packed, n_bits = batch.extract_frames(stego, delta, n_ac, mode="exact")
     assert np.array_equal(np.unpackbits(packed, count=n_bits), orc.batch_extract_bits(want, delta, n_ac))
-    # fast mode on the same content: identical extracted bits from the reference's frames, PSNR within tolerance
-    # except for the untouched-block artefact, which fast mode deliberately does not reproduce
-    packed, n_bits = batch.extract_frames(want, delta, n_ac, mode="fast")
-    got = np.unpackbits(packed, count=n_bits)
-    ref_bits = orc.batch_extract_bits(want, delta, n_ac)
-    ties = np.concatenate([near_tie_mask(f, delta, n_ac).reshape(-1) for f in want])
-    assert ties.mean() < 0.01 and np.array_equal(got[~ties], ref_bits[~ties])
+    # fast mode on the same content: identical extracted bits from the reference's frames and from the never-embedded
+    # cover (no masks: quantiser inputs near a tie take the exact path), stego PSNR within tolerance (blocks with a
+    # structurally zero change are replayed with the exact arithmetic)
+    for src in (want, cover):
+        packed, n_bits = batch.extract_frames(src, delta, n_ac, mode="fast")
+        assert np.array_equal(np.unpackbits(packed, count=n_bits), orc.batch_extract_bits(src, delta, n_ac))
+    fast, used_f = batch.embed_frames(cover, delta, n_ac, payload, mode="fast")
+    assert used_f == want_used
+    for k in range(2):
+        a, b = orc.psnr_u8(cover[k], fast[k]), orc.psnr_u8(cover[k], want[k])
+        assert abs(a - b) <= PSNR_TOL_DB, (k, a, b)
+        _REPORT[f"natural_like_n{n_ac}_d{delta}_frame{k}"] = {
+            "pixels": h * w, "pixels_differing_from_reference": int((fast[k] != want[k]).sum()), "psnr": a,
+            "psnr_reference": b}
+
+
+@pytest.mark.parametrize("n_ac,delta", CONTRACT_POINTS)
+def test_fast_mode_contract_on_structured_content(n_ac, delta):
+    """FAST embed on flat / letterboxed / one-dimensional / natural-like frames at 1080p: stego PSNR
+    within 0.01 dB of the oracle's, identical to the CPU build of the kernel header (which the CPU tier checks on the same
+    content), the reference's receiver reads the same bits from either stego frame, FAST extraction of stego, reference
+    stego and never-embedded cover equals the oracle's on every bit."""
+    h, w = 1080, 1920
+    for name, cover in structured_covers(h, w).items():
+        cap = batch.capacity_bits(1, h, w, n_ac)
+        payload = synth.synthetic_bits(cap, seed=n_ac * 100 + delta)
+        stego, used = batch.embed_frames(cover, delta, n_ac, payload, mode="fast")
+        _, ref, ref_used = orc.frame_embed(cover, delta, payload, n_ac)
+        assert used == ref_used == cap
+        a, b = orc.psnr_u8(cover, stego[0]), orc.psnr_u8(cover, ref)
+        assert abs(a - b) <= PSNR_TOL_DB, (name, a, b)
+        replayed = []
+        emu, _ = emu_embed(cover, delta, n_ac, payload, replayed=replayed)
+        assert np.array_equal(emu[0], stego[0]), name
+        if delta >= 8 and cover.min() >= 16 and cover.max() < 240:      # no clipping, delta >= 8: error-free (SURVEY N5)
+            assert np.array_equal(orc.frame_extract_bits(stego[0], delta, n_ac), payload), name
+        for src in (stego[0], ref, cover):
+            packed, n_bits = batch.extract_frames(src, delta, n_ac, mode="fast")
+            assert np.array_equal(np.unpackbits(packed, count=n_bits), orc.frame_extract_bits(src, delta, n_ac)), name
+        _REPORT[f"structured/{name}_n{n_ac}_d{delta}"] = {
+            "pixels": h * w, "pixels_differing_from_reference": int((stego[0] != ref).sum()), "psnr": a,
+            "psnr_reference": b, "blocks_replayed_exactly": replayed[0]}
+    # in place and through the device-pointer level: same frames
+    cover = np.stack(list(structured_covers(256, 512).values()))
+    f = cover.shape[0]
+    payload = synth.synthetic_bits(batch.capacity_bits(f, 256, 512, n_ac), seed=5)
+    want, _ = batch.embed_frames(cover, delta, n_ac, payload, mode="fast")
+    d_frames, d_bits = _Dev(cover.nbytes), _Dev(batch.pack_bits(payload).nbytes)
+    d_frames.put(cover)
+    d_bits.put(batch.pack_bits(payload))
+    planes = Planes.contiguous(f, 256, 512)
+    assert batch.embed_device(d_frames.ptr, d_frames.ptr, planes, delta, n_ac, d_bits.ptr, 0, payload.size) == payload.size
+    assert np.array_equal(d_frames.get().reshape(cover.shape), want)
 
 
 def test_golden_vectors(golden):
@@ -140,9 +175,6 @@ def test_golden_vectors(golden):
 
         _REPORT[name] = {"pixels": int(gray.size), "pixels_differing_from_reference": int((stego != ref_stego).sum()),
                          "psnr": orc.psnr_u8(gray, stego), "psnr_reference": info["psnr"]}
-        if name in NOISE_ONLY_CASES:
-            assert np.array_equal(stego, gray), name
-            continue
         assert used == info["used"] == ref_used, name
         # (c) a receiver running the reference reads the same bits from our frame as from the reference's
         assert np.array_equal(orc.frame_extract_bits(stego, delta, n_ac)[:used],
@@ -152,13 +184,11 @@ def test_golden_vectors(golden):
             assert abs(orc.psnr_u8(gray, stego) - info["psnr"]) <= PSNR_TOL_DB, name
         else:
             assert np.array_equal(stego, gray), name
-        # (e) extraction from the cover: identical except where c/delta sits on (or within float32 rounding of) a tie
+        # (e) extraction from the never-embedded cover: identical as well, rounding ties of c/delta included
         packed, n_bits = batch.extract_frames(gray, delta, n_ac, mode="fast")
-        cov = np.unpackbits(packed, count=n_bits)
-        want = golden_bits(arrays, name, "ext_cover", info["ext_cover_len"])
-        ties = near_tie_mask(gray, delta, n_ac).reshape(-1)
         _REPORT[name]["exact_ties_in_cover"] = int(exact_tie_mask(gray, delta, n_ac).sum())
-        assert np.array_equal(cov[~ties], want[~ties]), name
+        assert np.array_equal(np.unpackbits(packed, count=n_bits),
+                              golden_bits(arrays, name, "ext_cover", info["ext_cover_len"])), name
 
 
 def test_reference_ber_at_delta4_is_reproduced(golden):
@@ -253,7 +283,10 @@ def test_baseline_config5_shape_8k_delta_sweep(delta):
     assert np.array_equal(got, orc.frame_extract_bits(stego[0], delta, n_ac))
     assert abs(orc.psnr_u8(cover[0], stego[0]) - orc.psnr_u8(cover[0], ref_stego)) <= PSNR_TOL_DB
     ber = int((got != payload).sum())
-    assert ber == 0 if delta >= 8 else abs(ber - ref_ber) <= 0.05 * ref_ber
+    # the payload errors of OUR stego frame are exactly those the reference's receiver makes on it (asserted bit for bit
+    # above); against the reference's own stego frame the count can differ by the handful of pixels float32 noise decides
+    assert ber == int((orc.frame_extract_bits(stego[0], delta, n_ac) != payload).sum())
+    assert ber == 0 if delta >= 8 else abs(ber - ref_ber) <= 0.002 * ref_ber
     _REPORT[f"8k_n3_d{delta}"] = {"pixels": h * w, "pixels_differing_from_reference": int((stego[0] != ref_stego).sum()),
                                   "psnr": orc.psnr_u8(cover[0], stego[0]), "psnr_reference": orc.psnr_u8(cover[0], ref_stego),
                                   "payload_bit_errors": ber, "payload_bit_errors_reference": ref_ber}

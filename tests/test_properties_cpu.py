@@ -4,7 +4,7 @@ import numpy as np
 from hypothesis import HealthCheck, given, settings
 from hypothesis import strategies as st
 
-from testlib import emu_embed, emu_extract, near_tie_mask
+from testlib import emu_embed, emu_extract
 from oracle import qim_dct_oracle as orc
 
 DELTAS = st.sampled_from([1, 2, 3, 4, 5, 7.5, 8, 12, 16, 20, 33, 0.75, 100])
@@ -61,7 +61,7 @@ def test_exact_mode_equals_oracle_bit_for_bit(case):
 
 @settings(**COMMON)
 @given(cases())
-def test_fast_mode_bits_equal_oracle_away_from_rounding_ties(case):
+def test_fast_mode_bits_equal_oracle(case):
     frames, delta, n_ac, bits, off = case
     stego, used = emu_embed(frames, delta, n_ac, bits, bit_offset=off, exact=False)
     n = max(0, min(n_ac, 63))
@@ -70,6 +70,4 @@ def test_fast_mode_bits_equal_oracle_away_from_rounding_ties(case):
     for src in (stego, frames):
         got = emu_extract(src, delta, n_ac, exact=False)
         want = orc.batch_extract_bits(src, delta, n_ac)
-        ties = np.concatenate([near_tie_mask(fr, delta, n_ac).reshape(-1) for fr in src])
-        assert ties.size < 200 or ties.mean() < 0.2
-        assert np.array_equal(got[~ties], want[~ties])
+        assert np.array_equal(got, want)          # every bit, rounding ties included (exact path near ties)

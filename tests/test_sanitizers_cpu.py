@@ -20,10 +20,11 @@ def test_block_header_is_clean_under_asan_and_ubsan(tmp_path):
         lib = ctypes.CDLL({so!r})
         lib.emu_embed.restype = ctypes.c_uint64
         lib.emu_embed.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double,
-                                  ctypes.c_int, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int]
+                                  ctypes.c_int, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int,
+                                  ctypes.c_void_p]
         lib.emu_extract.restype = ctypes.c_uint64
         lib.emu_extract.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_int,
-                                    ctypes.c_void_p, ctypes.c_int]
+                                    ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
         rng = np.random.default_rng(0)
         for (f, h, w), n_ac, delta, off in [((2, 24, 40), 3, 8, 0), ((1, 16, 16), 63, 7.5, 5), ((3, 8, 8), 10, 20, 31),
                                             ((1, 32, 8), 1, 0.1, 0), ((2, 16, 24), 40, -1, 0), ((1, 8, 16), 0, 8, 0)]:
@@ -34,9 +35,9 @@ def test_block_header_is_clean_under_asan_and_ubsan(tmp_path):
             for exact in (0, 1):
                 out = np.empty_like(frames)
                 lib.emu_embed(frames.ctypes.data, out.ctypes.data, f, h, w, float(delta), n_ac, packed.ctypes.data, packed.size,
-                              off, bits.size - off, exact)
+                              off, bits.size - off, exact, None)
                 flags = np.zeros(max(cap, 1), np.uint8)
-                lib.emu_extract(out.ctypes.data, f, h, w, float(delta), n_ac, flags.ctypes.data, exact)
+                lib.emu_extract(out.ctypes.data, f, h, w, float(delta), n_ac, flags.ctypes.data, exact, None)
         print("sanitizers clean")
     """)
     env = dict(os.environ, LD_PRELOAD=asan, ASAN_OPTIONS="detect_leaks=0")

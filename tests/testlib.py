@@ -12,11 +12,38 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PKG_DIR = os.path.join(REPO, "secure-video-steganography-using-ecc-and-dct_amd")
 CSRC = os.path.join(PKG_DIR, "csrc")
 
-# Cases where the reference's output is shaped by pocketfft's float32 rounding noise alone: every
-# block is DCT->IDCT round-tripped with NO coefficient change, and truncation turns x-1e-5 into
-# x-1.  The HIP path adds an exactly-zero change to the integer pixels, so stego ==
-# gray there; DESIGN.md lists this as a deliberate deviation.
-NOISE_ONLY_CASES = {"G3_flat_zero_bits", "G3_flat_n63", "G5_delta0", "G5_delta_neg", "G5_n0"}
+def natural_like(h, w, seed):
+    """A frame with what real video has and uniform noise lacks: flat black bars, saturated highlights, smooth gradients,
+    low-amplitude texture - the content on which the reference's round-trip artefacts and clipping show."""
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:h, 0:w]
+    img = 128 + 90 * np.sin(xx / 97.0) * np.cos(yy / 61.0) + rng.normal(0, 2.0, (h, w))
+    img[: h // 8] = 0                      # letterbox
+    img[-h // 8:] = 16
+    img[h // 3: h // 2, w // 4: w // 2] = 255          # blown-out highlight
+    img[h // 2: h // 2 + 64, : w // 3] = 128            # flat mid-gray panel
+    return np.clip(np.rint(img), 0, 255).astype(np.uint8)
+
+
+def structured_covers(h, w, seed=0):
+    """name -> gray frame with structure that makes MANY blocks' coefficient changes structurally zero or integer-valued
+    (VERDICT r01 'What's weak' #1): there the reference's output is decided by pocketfft's round-trip noise."""
+    rng = np.random.default_rng(seed)
+    return {
+        "natural_like": natural_like(h, w, seed + 1),
+        "flat_128": np.full((h, w), 128, np.uint8),
+        "constant_rows": np.repeat(rng.integers(16, 240, (h, 1), dtype=np.uint8), w, axis=1),   # vertical structure only
+        "constant_columns": np.repeat(rng.integers(16, 240, (1, w), dtype=np.uint8), h, axis=0),
+        "half_letterbox": np.concatenate([np.full((h // 2, w), 16, np.uint8),
+                                          rng.integers(16, 240, (h - h // 2, w), dtype=np.uint8)]),
+        "checker_8": ((np.add.outer(np.arange(h) // 8, np.arange(w) // 8) % 2) * 200 + 20).astype(np.uint8),
+        "ramp": np.repeat((np.arange(w) // 4 % 256).astype(np.uint8)[None], h, axis=0),
+    }
+
+
+# (n_ac, delta) points of the FAST-mode contract checks on structured content (VERDICT r01 next #1) plus the settings at
+# which the index-4 / two-row coincidences are largest
+CONTRACT_POINTS = [(3, 8), (3, 16), (7, 4), (10, 20), (4, 8), (8, 4), (8, 2)]
 
 
 def sha(a):
@@ -71,23 +98,6 @@ def exact_tie_mask(gray, delta, n_ac):
     return mask
 
 
-def near_tie_mask(gray, delta, n_ac, tol=1e-3):
-    """Boolean [blocks, n] mask of coefficients whose float64 value lies within `tol` of a rounding tie
-    (k + 1/2) * delta.  FAST mode computes the coefficients with a different (equally accurate) float32
-    factorisation than pocketfft, so on frames that were never embedded the two can land on different sides of
-    a tie when the true value is within float32 rounding error (~1e-5) of it; `tol` is 100x that.  Includes the
-    exact ties of exact_tie_mask().  EXACT mode needs no mask."""
-    from scipy.fftpack import dct
-    n = max(0, min(int(n_ac), 63))
-    h, w = gray.shape
-    blocks = gray.reshape(h // 8, 8, w // 8, 8).transpose(0, 2, 1, 3).reshape(-1, 8, 8).astype(np.float64)
-    if delta <= 0 or n == 0:
-        return np.zeros((blocks.shape[0], n), bool)
-    c = dct(dct(blocks, axis=1, norm="ortho"), axis=2, norm="ortho").reshape(-1, 64)[:, 1:1 + n]
-    t = c / float(delta)
-    return np.abs(np.abs(t - np.rint(t)) - 0.5) * float(delta) < tol
-
-
 # ---- test-only CPU emulation of the per-block kernel arithmetic (tests/hostemu) ---------------
 _EMU = None
 
@@ -109,10 +119,10 @@ def hostemu():
     lib.emu_embed.restype = ctypes.c_uint64
     lib.emu_embed.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                               ctypes.c_double, ctypes.c_int, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64,
-                              ctypes.c_uint64, ctypes.c_int]
+                              ctypes.c_uint64, ctypes.c_int, ctypes.POINTER(ctypes.c_uint64)]
     lib.emu_extract.restype = ctypes.c_uint64
     lib.emu_extract.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double,
-                                ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
+                                ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_uint64)]
     lib.emu_pf_dct2.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
     lib.emu_pf_dct3.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
     lib.emu_forward_block.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
@@ -123,23 +133,32 @@ def hostemu():
     return lib
 
 
-def emu_embed(frames, delta, n_ac, bits, bit_offset=0, exact=False):
+def emu_embed(frames, delta, n_ac, bits, bit_offset=0, exact=False, replayed=None):
+    """`replayed`: optional list; receives the number of blocks FAST mode handed to the exact replay."""
     lib = hostemu()
     frames = np.ascontiguousarray(frames if frames.ndim == 3 else frames[None])
     f, h, w = frames.shape
     packed = np.packbits(np.asarray(bits, np.uint8))
     packed = np.concatenate([packed, np.zeros((-packed.size) % 4 + 4, np.uint8)])
     out = np.empty_like(frames)
+    count = ctypes.c_uint64(0)
     used = lib.emu_embed(frames.ctypes.data, out.ctypes.data, f, h, w, float(delta), int(n_ac),
-                         packed.ctypes.data, packed.size, int(bit_offset), int(len(bits) - bit_offset), int(exact))
+                         packed.ctypes.data, packed.size, int(bit_offset), int(len(bits) - bit_offset), int(exact),
+                         ctypes.byref(count))
+    if replayed is not None:
+        replayed.append(int(count.value))
     return out, int(used)
 
 
-def emu_extract(frames, delta, n_ac, exact=False):
+def emu_extract(frames, delta, n_ac, exact=False, redone=None):
+    """`redone`: optional list; receives the number of blocks FAST mode recomputed with the exact transform."""
     lib = hostemu()
     frames = np.ascontiguousarray(frames if frames.ndim == 3 else frames[None])
     f, h, w = frames.shape
     n = max(0, min(int(n_ac), 63))
     out = np.zeros(f * (h // 8) * (w // 8) * n, np.uint8)
-    lib.emu_extract(frames.ctypes.data, f, h, w, float(delta), int(n_ac), out.ctypes.data, int(exact))
+    count = ctypes.c_uint64(0)
+    lib.emu_extract(frames.ctypes.data, f, h, w, float(delta), int(n_ac), out.ctypes.data, int(exact), ctypes.byref(count))
+    if redone is not None:
+        redone.append(int(count.value))
     return out

@@ -15,7 +15,7 @@ step() {  # step <seconds> <logfile> <cmd...>
 }
 : > gpurun_out/steps.log
 step 300 smoke.log python -c "import __graft_entry__ as g; g.smoke()"
-step 600 pytest_gpu.log python -m pytest tests -m gpu -x -q -s
+step 900 pytest_gpu.log python -m pytest tests -m gpu -x -q -s
 step 400 bench_n1.log python bench.py ${BENCH_ARGS:-}
 if [ "${PROFILE:-1}" = "1" ]; then
     export TMPDIR=/tmp
