@@ -48,7 +48,27 @@ def parse_args():
     ap.add_argument("--rehearse-gloo", action="store_true",
                     help="rank-logic rehearsal on a box with fewer GPUs than ranks: gloo backend, ranks share "
                          "GPUs, collectives staged through host memory (numbers are NOT bench results)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="take the process-group path (RCCL gather included) even with one rank, so that a one-GPU box "
+                         "exercises the collective calls")
     return ap.parse_args()
+
+
+def launch_ranks(args) -> int:
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves - one process per GPU through
+    torch.distributed.run, rendezvous on 127.0.0.1 - and relay what they print (rank 0's JSON line).  Runs BEFORE this
+    process imports torch or touches HIP: the parent only waits.  -> exit code of the launcher."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    if args.force_dist:
+        env["SVS_BENCH_FORCE_DIST"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
 
 
 def _cpu_worker(task):
@@ -108,6 +128,8 @@ def cpu_baseline_all_cores(args):
 
 def main():
     args = parse_args()
+    if "RANK" not in os.environ and (args.gpus > 1 or args.force_dist):
+        raise SystemExit(launch_ranks(args))             # parent of the ranks: never initialises the GPU
     cpu_parallel = None
     if args.cpu_frames > 0 and int(os.environ.get("WORLD_SIZE", "1")) == 1:
         cpu_parallel = cpu_baseline_all_cores(args)          # before the first HIP call of this process
@@ -121,7 +143,7 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     # launched by torch.distributed.run (RANK set): take the collective path even with one rank, so a
     # 1-GPU box can exercise the RCCL calls; plain `python bench.py` is the N = 1 line without a process group
-    use_dist = world > 1 or (os.environ.get("SVS_BENCH_FORCE_DIST") == "1" and "RANK" in os.environ)
+    use_dist = world > 1 or ((args.force_dist or os.environ.get("SVS_BENCH_FORCE_DIST") == "1") and "RANK" in os.environ)
     if args.rehearse_gloo:
         local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
@@ -265,16 +287,21 @@ def main():
         embed_bytes = F * H * W * 2 + nbytes            # read u8 + write u8 + packed payload
         extract_bytes = F * H * W + nbytes
         achieved = embed_bytes / (embed_ms * 1e-3) / 1e9
-        traffic = None
+        # HBM bytes per embed launch from the PMC counters: NOT measured in this run (counters need their own rocprofv3
+        # --pmc passes, tools/gpu_pmc.sh); taken from the committed summary of those passes when it is for this workload
+        traffic, traffic_source = None, None
         tpath = os.path.join(REPO, "profiles", "hbm_traffic.json")
         if os.path.exists(tpath):
             try:
                 with open(tpath) as fh:
                     tj = json.load(fh)
-                if tj.get("frames") == F and tj.get("height") == H and tj.get("width") == W:
+                if tj.get("frames") == F and tj.get("height") == H and tj.get("width") == W and tj.get("n_ac", 3) == n_ac:
                     traffic = tj.get("embed_bytes_per_launch")
+                    traffic_source = {"file": "profiles/hbm_traffic.json", "captured": tj.get("captured"),
+                                      "how": "rocprofv3 --pmc passes of this bench command (tools/gpu_pmc.sh), "
+                                             "2 x FETCH_SIZE + WRITE_SIZE per embed launch; not measured in this run"}
             except Exception:
-                traffic = None
+                traffic, traffic_source = None, None
         result = {
             "metric": "Mpixels/sec embed+extract round-trip at 4K; payload bit-error rate (must be 0)",
             "value": mpix_s, "unit": "Mpix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -289,7 +316,7 @@ def main():
             "psnr_frame0_db": psnr0,
             "kernel_ms": {"embed": embed_ms, "extract": extract_ms},
             "roofline": {"bound": "hbm", "kernel": "embed_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "algorithmic_bytes_per_launch": embed_bytes,
                          "extract_achieved": extract_bytes / (extract_ms * 1e-3) / 1e9},
         }

@@ -35,15 +35,19 @@ def bitstream_ke_bytes(bitstream_data: str) -> bytes:
             raise ValueError("Bitstream kosong setelah dipotong.")
     if not bitstream_data:
         return b""
-    return np.packbits(_checked_bits(bitstream_data)).tobytes()
-
-
-def _checked_bits(text: str) -> np.ndarray:
-    bits = _batch.str_to_bits(text)
-    if bits.size and bits.max() > 1:
-        bad = next(ch for ch in text if ch not in "01")
-        raise ValueError(f"invalid literal for int() with base 2: {bad!r}")
-    return bits
+    try:
+        bits = _batch.str_to_bits(bitstream_data)
+        clean = bits.max() <= 1
+    except UnicodeEncodeError:
+        clean = False
+    if clean:
+        return np.packbits(bits).tobytes()
+    # something other than '0'/'1' in the string: byte by byte through int(), whose rules decide what is accepted
+    # (' 0101010' is) and what the ValueError says (it quotes the whole 8-character group)
+    out = bytearray()
+    for start in range(0, len(bitstream_data), 8):
+        out.append(int(bitstream_data[start:start + 8], 2))
+    return bytes(out)
 
 
 def int_ke_bitstream(nilai_int: int, jumlah_bit: int) -> str:

@@ -20,8 +20,10 @@ from config_and_setup import (bitstream_ke_bytes, buat_pasangan_kunci_ecc, buat_
                               serialisasi_kunci_publik_ecc_compressed, setup_kunci_ecc)  # noqa: F401
 from svsdct import batch as _batch
 from svsdct import framing as _framing
+from svsdct.pipeline import FramePipeline
 
 BATCH_FRAMES = int(os.environ.get("SVS_BATCH_FRAMES", "32"))
+PIPELINE_DEPTH = int(os.environ.get("SVS_PIPELINE_DEPTH", "3"))     # batches in flight between decode and encode
 # SVS_FUSED_COLOUR=1: colour frames go to the GPU as they are and BGR -> gray -> embed -> BGR runs as ONE kernel
 # (svs_embed_bgr_dev) instead of cv2.cvtColor on the host either side of the operator (:117-126).  Only used when the
 # device conversion reproduces this machine's cv2 bit for bit (svsdct.colour); otherwise the host conversion stays.
@@ -121,51 +123,98 @@ def embed_gambar_ke_video_final(path_video_input, path_gambar_rahasia, path_vide
             print(f"    Info: jalur warna terfusi tidak dipakai ({exc}).")
     per_frame = _batch.capacity_bits(1, out_h, out_w, num_ac_coeffs)
     usable = per_frame if delta_kuantisasi > 0 else 0              # nothing can be embedded otherwise (:143-145)
-    disisipkan, frame_num, selesai = 0, 0, False
-    first_gray = first_stego = None
-    while not selesai:
-        # gather the next batch of frames that will carry payload
-        want = BATCH_FRAMES if usable == 0 else min(BATCH_FRAMES, -(-(total_bits - disisipkan) // usable))
-        grays = []
-        while len(grays) < want:
+    state = {"disisipkan": 0, "frame_num": 0, "first": None}
+
+    def baca(n):
+        """decode up to n frames, cropped; gray unless the fused colour path takes them as they are"""
+        frames = []
+        while len(frames) < n:
             ok, frame_bgr = cap.read()
             if not ok:
                 break
             potong = frame_bgr[0:out_h, 0:out_w]
-            grays.append(potong if tabel_warna else cv2.cvtColor(potong, cv2.COLOR_BGR2GRAY))
-        if not grays:
-            print(f"    Warning: Video selesai sebelum semua payload ({total_bits} bits) disisipkan.")
-            break
-        stack = np.stack(grays)
-        expect = min(len(grays) * usable, total_bits - disisipkan)
-        if tabel_warna:
-            stego_bgr, stack, used = _batch.embed_bgr_frames(stack, delta_kuantisasi, num_ac_coeffs, payload,
-                                                             bit_offset=disisipkan, n_bits=total_bits - disisipkan,
-                                                             weights=tabel_warna)
-            stego = stego_bgr[..., 0]
-        else:
-            stego_bgr = None
-            stego, used = _batch.embed_frames(stack, delta_kuantisasi, num_ac_coeffs, payload,
-                                              bit_offset=disisipkan, n_bits=total_bits - disisipkan)
-        if used != expect:
-            raise RuntimeError(f"embed kernel consumed {used} bits, expected {expect}")
-        for k in range(len(grays)):
-            frame_num += 1
-            bits_frame = min(usable, total_bits - disisipkan)
-            if frame_num == 1:
-                first_gray, first_stego = stack[0].copy(), stego[0].copy()
-            writer.write(stego_bgr[k] if stego_bgr is not None else cv2.cvtColor(stego[k], cv2.COLOR_GRAY2BGR))
-            disisipkan += bits_frame
-            print(f"    Frame {frame_num}: {bits_frame} bits disisipkan. Total disisipkan: {disisipkan}/{total_bits}")
-        if disisipkan >= total_bits:
-            selesai = True
-            print("    Semua payload (SHA3-ECC-AES) berhasil disisipkan!")
-            while True:                                            # remaining frames: copied, in colour (:134-139)
-                ok, frame_bgr = cap.read()
-                if not ok:
+            frames.append(potong if tabel_warna else cv2.cvtColor(potong, cv2.COLOR_BGR2GRAY))
+        return frames
+
+    def tulis(gray_stack, stego_stack, stego_bgr=None):
+        """encode one finished batch, one log line per frame as the reference prints them (:129)"""
+        for k in range(len(stego_stack)):
+            state["frame_num"] += 1
+            bits_frame = min(usable, total_bits - state["disisipkan"])
+            if state["frame_num"] == 1:
+                state["first"] = (np.array(gray_stack[0]), np.array(stego_stack[0]))
+            writer.write(stego_bgr[k] if stego_bgr is not None else cv2.cvtColor(stego_stack[k], cv2.COLOR_GRAY2BGR))
+            state["disisipkan"] += bits_frame
+            print(f"    Frame {state['frame_num']}: {bits_frame} bits disisipkan. "
+                  f"Total disisipkan: {state['disisipkan']}/{total_bits}")
+
+    # frames that carry payload: frame k takes stream bits [k*cap, (k+1)*cap) (:116-128), so their number is known now
+    carrying = -(-total_bits // usable) if usable else None        # None: every frame is entered, nothing is consumed
+    habis = False
+    if tabel_warna:
+        # fused colour path (opt-in): synchronous batches through svs_embed_bgr
+        sisa = carrying
+        while not habis and (sisa is None or sisa > 0):
+            frames = baca(BATCH_FRAMES if sisa is None else min(BATCH_FRAMES, sisa))
+            if not frames:
+                habis = True
+                break
+            stego_bgr, gray, used = _batch.embed_bgr_frames(np.stack(frames), delta_kuantisasi, num_ac_coeffs, payload,
+                                                            bit_offset=state["disisipkan"],
+                                                            n_bits=total_bits - state["disisipkan"], weights=tabel_warna)
+            expect = min(len(frames) * usable, total_bits - state["disisipkan"])
+            if used != expect:
+                raise RuntimeError(f"embed kernel consumed {used} bits, expected {expect}")
+            tulis(gray, stego_bgr[..., 0], stego_bgr)
+            if sisa is not None:
+                sisa -= len(frames)
+    else:
+        # Overlapped staging (SURVEY 8(f) rank 4): batch k+1 is decoded while batch k is on the GPU (H2D copy, kernel and
+        # D2H copy run asynchronously on the slot's stream) and batch k-1 is encoded; the payload is uploaded once.
+        per_batch = BATCH_FRAMES if carrying is None else max(1, min(BATCH_FRAMES, carrying))
+        n_batches = PIPELINE_DEPTH if carrying is None else -(-carrying // per_batch)
+        with FramePipeline(out_h, out_w, per_batch, delta_kuantisasi, num_ac_coeffs,
+                           depth=max(1, min(PIPELINE_DEPTH, n_batches)), mode=_batch.host_level_mode()) as pipe:
+            pipe.set_payload(payload)
+            pending = []                                               # (slot, gray frames, bits expected) in flight
+            sisa, k = carrying, 0
+
+            def selesaikan():
+                slot, gray, expect, used = pending.pop(0)
+                if used != expect:
+                    raise RuntimeError(f"embed kernel consumed {used} bits, expected {expect}")
+                tulis(gray, pipe.embed_result(slot))
+
+            while sisa is None or sisa > 0:
+                slot = k % pipe.depth
+                if len(pending) == pipe.depth:
+                    selesaikan()                                       # frees this slot
+                frames = baca(per_batch if sisa is None else min(per_batch, sisa))
+                if not frames:
+                    habis = True
                     break
-                frame_num += 1
-                writer.write(frame_bgr[0:out_h, 0:out_w])
+                gray = np.stack(frames)
+                np.copyto(pipe.input(slot)[:len(frames)], gray)
+                offset = k * per_batch * usable
+                used = pipe.submit_embed(slot, len(frames), bit_offset=min(offset, total_bits))
+                pending.append((slot, gray, min(len(frames) * usable, max(0, total_bits - offset)), used))
+                if sisa is not None:
+                    sisa -= len(frames)
+                k += 1
+            while pending:
+                selesaikan()
+    disisipkan = state["disisipkan"]
+    selesai = usable > 0 and disisipkan >= total_bits
+    if selesai:
+        print("    Semua payload (SHA3-ECC-AES) berhasil disisipkan!")
+        while True:                                                    # remaining frames: copied, in colour (:134-139)
+            ok, frame_bgr = cap.read()
+            if not ok:
+                break
+            writer.write(frame_bgr[0:out_h, 0:out_w])
+    else:
+        print(f"    Warning: Video selesai sebelum semua payload ({total_bits} bits) disisipkan.")
+    first_gray, first_stego = state["first"] if state["first"] else (None, None)
     cap.release()
     writer.release()
     if selesai:

@@ -18,8 +18,10 @@ from config_and_setup import (bytes_ke_bitstream, buat_shared_secret_ecdh, dekri
                               hitung_sha3_256, setup_kunci_ecc)  # noqa: F401
 from svsdct import batch as _batch
 from svsdct import framing as _framing
+from svsdct.pipeline import FramePipeline
 
 BATCH_FRAMES = int(os.environ.get("SVS_BATCH_FRAMES", "32"))
+PIPELINE_DEPTH = int(os.environ.get("SVS_PIPELINE_DEPTH", "3"))     # batches in flight between decode and the kernels
 _MIN_HEADER_BITS = _framing.HEADER_BITS_STANDARD        # 976 (extract_process.py:51-53)
 # SVS_FUSED_COLOUR=1: bits are extracted straight from the colour frames (svs_extract_bgr_dev) when the device
 # BGR -> gray reproduces this machine's cv2 (svsdct.colour); see embed_process.py
@@ -121,22 +123,63 @@ def ekstraksi_gambar_video_final(path_stego_video, path_gambar_output,
     ct_bits = stream[hdr.bits:]
     if ct_bits.size < butuh:
         print(f"    Ciphertext belum lengkap ({ct_bits.size}/{butuh} bits). Melanjutkan ke frame berikutnya...")
-        while ct_bits.size < butuh:
-            lagi = min(BATCH_FRAMES, -(-(butuh - ct_bits.size) // max(per_frame, 1)))
-            grays = []
-            while len(grays) < lagi:
-                gray = baca_gray()
-                if gray is None:
+        lagi = -(-(butuh - ct_bits.size) // max(per_frame, 1))      # frames still needed: known from the header
+        pieces = [ct_bits]
+        if tabel_warna:
+            # fused colour path (opt-in): synchronous batches through svs_extract_bgr
+            while lagi > 0:
+                grays = []
+                while len(grays) < min(BATCH_FRAMES, lagi):
+                    gray = baca_gray()
+                    if gray is None:
+                        break
+                    grays.append(gray)
+                if not grays:
+                    print("    Warning: Video selesai sebelum semua ciphertext diekstrak.")
                     break
-                grays.append(gray)
-            if not grays:
-                print("    Warning: Video selesai sebelum semua ciphertext diekstrak.")
-                break
-            bits = _extract_frames(grays, delta_kuantisasi, num_ac_coeffs, tabel_warna)   # one launch per batch
-            ct_bits = np.concatenate([ct_bits, bits])
-            frame_num += len(grays)
-            print(f"    Sisa ciphertext diekstrak sampai frame {frame_num}. "
-                  f"Total bit ciphertext terkumpul: {ct_bits.size}")
+                pieces.append(_extract_frames(grays, delta_kuantisasi, num_ac_coeffs, tabel_warna))
+                lagi -= len(grays)
+                frame_num += len(grays)
+                print(f"    Sisa ciphertext diekstrak sampai frame {frame_num}. "
+                      f"Total bit ciphertext terkumpul: {sum(p.size for p in pieces)}")
+        else:
+            # overlapped staging: batch k+1 is decoded while batch k is copied to the GPU, extracted and copied back
+            per_batch = max(1, min(BATCH_FRAMES, lagi))
+            with FramePipeline(h, w, per_batch, delta_kuantisasi, num_ac_coeffs,
+                               depth=max(1, min(PIPELINE_DEPTH, -(-lagi // per_batch))),
+                               mode=_batch.host_level_mode()) as pipe:
+                pending, k = [], 0
+
+                def kumpulkan():
+                    nonlocal frame_num
+                    slot, n_frames = pending.pop(0)
+                    packed, n_bits = pipe.extract_result(slot)
+                    pieces.append(np.unpackbits(packed, count=n_bits))
+                    frame_num += n_frames
+                    print(f"    Sisa ciphertext diekstrak sampai frame {frame_num}. "
+                          f"Total bit ciphertext terkumpul: {sum(p.size for p in pieces)}")
+
+                while lagi > 0:
+                    slot = k % pipe.depth
+                    if len(pending) == pipe.depth:
+                        kumpulkan()
+                    grays = []
+                    while len(grays) < min(per_batch, lagi):
+                        gray = baca_gray()
+                        if gray is None:
+                            break
+                        grays.append(gray)
+                    if not grays:
+                        print("    Warning: Video selesai sebelum semua ciphertext diekstrak.")
+                        break
+                    np.copyto(pipe.input(slot)[:len(grays)], np.stack(grays))
+                    pipe.submit_extract(slot, len(grays))
+                    pending.append((slot, len(grays)))
+                    lagi -= len(grays)
+                    k += 1
+                while pending:
+                    kumpulkan()
+        ct_bits = np.concatenate(pieces)
     if ct_bits.size < butuh:
         print("  Ekstraksi GAGAL: Ciphertext tidak lengkap.")
         cap.release()

@@ -40,6 +40,13 @@ def mode_flags(mode, default: str) -> int:
     raise ValueError(f"unknown transform mode {mode!r} (use 'fast' or 'exact')")
 
 
+def host_level_mode() -> str:
+    """transform mode of the NumPy-level entry points and of the drop-in pipelines built on them"""
+    mode = _ENV_MODE or "exact"
+    mode_flags(mode, "exact")       # validates
+    return mode
+
+
 def clamp_ac(n_ac) -> int:
     return max(0, min(int(n_ac), MAX_AC))  # config_and_setup.py:138
 

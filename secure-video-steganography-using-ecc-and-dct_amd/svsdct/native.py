@@ -8,6 +8,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import threading
 
 _PKG_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.environ.get("SVSDCT_LIB", os.path.join(_PKG_DIR, "lib", "libsvsdct.so"))
@@ -117,15 +118,17 @@ def check(rc: int, what: str) -> None:
         raise SvsNativeError(f"{what} failed ({rc}): {msg}", rc)
 
 
-_initialised = set()
+_current = threading.local()      # hipSetDevice is per host thread: remember what THIS thread last selected
 
 
 def ensure_device(device: int = 0) -> None:
-    """svs_init(device) once per process/device; raises when no GPU is usable."""
-    if device in _initialised:
+    """Make `device` the calling thread's HIP device (svs_init = hipSetDevice + a usability check) unless this thread
+    selected it already; raises when no GPU is usable.  A process that alternates devices, or a new thread, is
+    switched explicitly instead of silently running on whatever device was current."""
+    if getattr(_current, "device", None) == device:
         return
     check(load().svs_init(device), f"svs_init({device})")
-    _initialised.add(device)
+    _current.device = device
 
 
 def device_arch(device: int = 0) -> str:

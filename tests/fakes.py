@@ -3,6 +3,7 @@ build image (cv2, cryptography).  They implement just the calls the drop-in pipe
 in-memory videos, so the frame-loop / framing logic can be exercised here; nothing in the product
 imports this file."""
 import hashlib
+import time
 import types
 
 import numpy as np
@@ -31,6 +32,9 @@ def make_fake_cv2():
         def read(self):
             if self.video is None or self.pos >= len(self.video["frames"]):
                 return False, None
+            if self.video.get("read_delay"):                       # a slow decoder
+                time.sleep(self.video["read_delay"])
+            self.video.setdefault("read_times", []).append(time.perf_counter())
             self.pos += 1
             return True, self.video["frames"][self.pos - 1].copy()
 
@@ -137,3 +141,53 @@ def dekripsi_aes_gcm(ct, key, nonce, tag):
 CRYPTO_NAMES = ["buat_pasangan_kunci_ecc", "serialisasi_kunci_publik_ecc_compressed",
                 "deserialisasi_kunci_publik_ecc_compressed", "buat_shared_secret_ecdh",
                 "derive_kunci_aes_dari_shared_secret", "enkripsi_aes_gcm", "dekripsi_aes_gcm"]
+
+
+# ---- stand-in for svsdct.pipeline.FramePipeline over the CPU build of the kernel header (CPU tier only) -------------
+class EmuFramePipeline:
+    """Same interface and batch bookkeeping as svsdct.pipeline.FramePipeline; the work is done synchronously by
+    tests/hostemu at submit time.  Lets the CPU tier run the drop-in frame loops without a GPU."""
+
+    def __init__(self, height, width, batch_frames, delta, n_ac, depth=3, mode=None, device=0):
+        from svsdct import batch
+        self.h, self.w, self.batch, self.depth = height, width, batch_frames, depth
+        self.delta, self.n_ac, self.exact = delta, n_ac, (mode or "fast") == "exact"
+        self.frame_capacity = batch.capacity_bits(1, height, width, n_ac)
+        self.batch_capacity = self.frame_capacity * batch_frames
+        self._in = [np.zeros((batch_frames, height, width), np.uint8) for _ in range(depth)]
+        self._out = [None] * depth
+        self._payload = np.zeros(0, np.uint8)
+
+    def set_payload(self, bits):
+        self._payload = np.asarray(bits, np.uint8).copy()
+
+    def input(self, slot):
+        return self._in[slot]
+
+    def submit_embed(self, slot, n_frames, bit_offset):
+        from testlib import emu_embed
+        stego, used = emu_embed(self._in[slot][:n_frames].copy(), self.delta, self.n_ac, self._payload,
+                                bit_offset=min(bit_offset, self._payload.size), exact=self.exact)
+        self._out[slot] = stego
+        return used
+
+    def embed_result(self, slot):
+        return self._out[slot]
+
+    def submit_extract(self, slot, n_frames):
+        from testlib import emu_extract
+        flags = emu_extract(self._in[slot][:n_frames].copy(), self.delta, self.n_ac, exact=self.exact)
+        self._out[slot] = (np.packbits(flags), int(flags.size))
+        return int(flags.size)
+
+    def extract_result(self, slot):
+        return self._out[slot]
+
+    def close(self):
+        pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()

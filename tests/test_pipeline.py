@@ -37,6 +37,8 @@ def _install(monkeypatch, backend):
             return np.packbits(flags), int(flags.size)
         monkeypatch.setattr(batch, "embed_frames", embed_frames)
         monkeypatch.setattr(batch, "extract_frames", extract_frames)
+        monkeypatch.setattr(embed_process, "FramePipeline", fakes.EmuFramePipeline)
+        monkeypatch.setattr(extract_process, "FramePipeline", fakes.EmuFramePipeline)
     fakes.VIDEOS.clear()
     return embed_process, extract_process
 
@@ -126,8 +128,117 @@ def test_payload_spread_over_many_frames_and_batches(monkeypatch, tmp_path, back
     assert ok                                                           # 976 + 1536 = 2512 bits -> 7 frames
     out = fakes.VIDEOS[str(tmp_path / "s.avi")]["frames"]
     assert np.array_equal(out[7], frames[7]) and not np.array_equal(out[6], frames[6])
+    # the overlapped, batched loop writes exactly the frames a frame-by-frame loop over the reference operator writes
+    # (the pipelines run the pocketfft-identical arithmetic): three batches of 3 / 3 / 1 frames through 3 slots
+    cv2 = sys.modules["cv2"]
+    gray_in = np.stack([cv2.cvtColor(f[:32, :48], cv2.COLOR_BGR2GRAY) for f in frames[:7]])
+    stream = orc.batch_extract_bits(np.stack([f[..., 0] for f in out[:7]]), delta, n_ac)[:976 + 1536]
+    want, used = orc.batch_embed(gray_in, delta, stream, n_ac)
+    assert used == 2512
+    for k in range(7):
+        assert np.array_equal(out[k][..., 0], want[k]), k
     assert ext.ekstraksi_gambar_video_final(str(tmp_path / "s.avi"), str(tmp_path / "o.png"), delta, n_ac, receiver)
     assert np.array_equal(np.asarray(Image.open(str(tmp_path / "o.png"))), secret)
+
+
+@pytest.mark.gpu
+def test_decode_overlaps_the_gpu_work(monkeypatch, tmp_path):
+    """SURVEY 8(f) rank 4 wired into the drop-in loops: with a slow decoder the next batch is being decoded while the
+    previous one is on the GPU.  Structural check: frames of batch k+1 are read before batch k's result is collected;
+    timing check: three slots in flight finish sooner than one slot (decode, then wait for the GPU, then decode ...)."""
+    import time
+    from svsdct import pipeline as pl
+    emb, ext = _install(monkeypatch, "gpu")
+    monkeypatch.setattr(emb, "BATCH_FRAMES", 8)
+    h, w, n_frames, n_ac, delta = 1080, 1920, 48, 3, 8
+    rng = np.random.default_rng(1)
+    base = rng.integers(16, 240, (h, w, 3), dtype=np.uint8)
+    frames = [np.roll(base, k, axis=1) for k in range(n_frames)]
+    secret_path = str(tmp_path / "big.png")
+    per_frame = (h // 8) * (w // 8) * n_ac                                    # 97 200 bits per frame
+    side = int(np.sqrt((40 * per_frame - 976) // 8))                           # payload over ~40 frames = 5 batches
+    Image.fromarray(rng.integers(0, 256, (side, side), dtype=np.uint8), mode="L").save(secret_path)
+    pub = fakes.serialisasi_kunci_publik_ecc_compressed(fakes.FakeKey(b"bob").public())
+    collected = []
+    real_result = pl.FramePipeline.embed_result
+
+    def spy(self, slot):
+        collected.append(time.perf_counter())
+        return real_result(self, slot)
+    monkeypatch.setattr(pl.FramePipeline, "embed_result", spy)
+    elapsed = {}
+    for depth in (1, 3, 1, 3):
+        monkeypatch.setattr(emb, "PIPELINE_DEPTH", depth)
+        fakes.VIDEOS.clear()
+        fakes.VIDEOS["in.mp4"] = {"frames": frames, "fps": 24.0, "read_delay": 0.002}
+        collected.clear()
+        t0 = time.perf_counter()
+        ok, _, _ = emb.embed_gambar_ke_video_final("in.mp4", secret_path, str(tmp_path / f"o{depth}"), delta, n_ac, pub)
+        elapsed.setdefault(depth, []).append(time.perf_counter() - t0)
+        assert ok
+        reads = fakes.VIDEOS["in.mp4"]["read_times"]
+        if depth == 3:
+            # batch 1 (frames 8..15) was decoded before batch 0's stego frames were collected
+            assert reads[15] < collected[0]
+        else:
+            assert reads[8] > collected[0]
+    a = np.array_equal(fakes.VIDEOS[str(tmp_path / "o1.avi")]["frames"][5], fakes.VIDEOS[str(tmp_path / "o3.avi")]["frames"][5])
+    assert a
+    assert min(elapsed[3]) < min(elapsed[1]), elapsed
+    import json, os
+    from testlib import REPO
+    os.makedirs(os.path.join(REPO, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(REPO, "gpurun_out", "pipeline_overlap.json"), "w") as fh:
+        json.dump({"frames": n_frames, "shape": [h, w], "decode_delay_s_per_frame": 0.002, "batch_frames": 8,
+                   "elapsed_s_depth1": elapsed[1], "elapsed_s_depth3": elapsed[3]}, fh)
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_reference_built_payload_and_shipped_secret_image(monkeypatch, tmp_path, backend):
+    """Fixtures produced by the REFERENCE's helpers (tests/golden/make_framing_golden.py): (1) the 976-bit header +
+    ciphertext stream they assemble (embed_process.py:62-74) goes through embed -> extract on the frame operator and
+    parses back to the same fields; (2) the shipped secret image (media/input/image64.png as 'L' pixels) travels through
+    both drop-in pipelines and comes out as media/output/extracted_image_gui.png did from the reference's own GUI run."""
+    import hashlib
+    import json
+    import os
+    from testlib import REPO
+    gold = os.path.join(REPO, "tests", "golden")
+    with open(os.path.join(gold, "framing_golden.json")) as fh:
+        meta = json.load(fh)
+    arr = np.load(os.path.join(gold, "framing_golden.npz"), allow_pickle=False)
+    emb, ext = _install(monkeypatch, backend)
+    info = meta["header"]["secret_64x64"]
+    stream = np.unpackbits(arr["header/secret_64x64/payload_bits"], count=info["n_bits"])
+    h, w, n_ac, delta = 96, 160, 10, 8                                       # 240 blocks -> 2 400 bits per frame
+    n_frames = -(-stream.size // 2400)
+    cover = synth.synthetic_frames(n_frames, h, w, seed=64)
+    if backend == "gpu":
+        stego, used = batch.embed_frames(cover, delta, n_ac, stream, mode="fast")
+        packed, n_bits = batch.extract_frames(stego, delta, n_ac, mode="fast")
+        got = np.unpackbits(packed, count=n_bits)
+    else:
+        stego, used = emu_embed(cover, delta, n_ac, stream)
+        got = emu_extract(stego, delta, n_ac)
+    assert used == stream.size and np.array_equal(got[:used], stream)
+    hdr = framing.parse_header(got)
+    f = {k: bytes.fromhex(v) for k, v in info["fields_hex"].items()}
+    assert (hdr.width, hdr.height, hdr.eph_pub, hdr.salt, hdr.digest, hdr.nonce, hdr.tag, hdr.bits) == \
+        (64, 64, f["eph_pub"], f["salt"], f["digest"], f["nonce"], f["tag"], 976)
+    assert np.packbits(got[976:976 + 8 * hdr.ciphertext_len]).tobytes() == arr["header/secret_64x64/ciphertext"].tobytes()
+
+    secret_path = str(tmp_path / "image64_L.png")
+    Image.fromarray(arr["media/image64_L"], mode="L").save(secret_path)
+    frames = [np.stack([synth.synthetic_frames(1, 120, 160, seed=3 + c, first_frame=k)[0] for c in range(3)], -1)
+              for k in range(14)]
+    fakes.VIDEOS["cover.mp4"] = {"frames": frames, "fps": 24.0}
+    receiver = fakes.FakeKey(b"bob")
+    pub = fakes.serialisasi_kunci_publik_ecc_compressed(receiver.public())
+    assert emb.embed_gambar_ke_video_final("cover.mp4", secret_path, str(tmp_path / "s"), 20, 10, pub)[0]   # GUI defaults
+    assert ext.ekstraksi_gambar_video_final(str(tmp_path / "s.avi"), str(tmp_path / "extracted.png"), 20, 10, receiver)
+    out = Image.open(str(tmp_path / "extracted.png"))
+    assert out.mode == meta["media"]["extracted_mode"] and list(out.size) == meta["media"]["extracted_size"]
+    assert hashlib.sha256(np.asarray(out).tobytes()).hexdigest() == meta["media"]["extracted_image_gui_sha256"]
 
 
 @pytest.mark.gpu
