@@ -29,6 +29,14 @@
 #define SVS_HD inline
 #endif
 
+// compiler scheduling fence (device only): nothing is moved across it.  Used to keep the instruction scheduler from
+// hoisting whole passes of independent work (and their live registers) ahead of where they are consumed.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define SVS_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define SVS_SCHED_FENCE() ((void)0)
+#endif
+
 namespace svs {
 
 // A block is held as two arrays of 8 little-endian dwords: rx[y] = pixels 0..3 of row y,
@@ -772,6 +780,89 @@ SVS_HD void embed_block_exact(uint32_t (&rx)[8], uint32_t (&ry)[8], uint32_t n, 
             rx[2 * q + k] = lo4;
             ry[2 * q + k] = hi4;
         }
+    }
+}
+
+// EXACT embed of TWO horizontally adjacent blocks at once: every value is a pair (block A, block B) and every transform
+// instruction a packed-FP32 one (v_pk_add / v_pk_mul / v_pk_fma_f32, each component rounding exactly like the scalar
+// operation).  Unlike embed_block_exact - which pairs two LINES of one block and has to transpose 2x2 sub-blocks between
+// the passes - the two blocks never exchange data, so the packed form costs no extra instructions: 2 x 928 scalar transform
+// operations become 928 packed ones.  Same results as two embed_block_exact calls, bit for bit.
+template <int U, int QM>
+SVS_HD void embed_block_exact_pair(uint32_t (&ax)[8], uint32_t (&ay)[8], uint32_t (&bx)[8], uint32_t (&by)[8], uint32_t n,
+                                   uint32_t nb_a, uint32_t nb_b, uint32_t hi_a, uint32_t lo_a, uint32_t hi_b, uint32_t lo_b,
+                                   const QimParams &qp) {
+    using pf::f32x2;
+    f32x2 D[8][8];  // D[u][v] = (coefficient of A, coefficient of B)
+    {
+        f32x2 V[8][8];  // after the vertical pass: V[u][x]
+#define SVS_COL2(X, WA, WB, B)                                                          \
+    {                                                                                   \
+        f32x2 col[8], out[8];                                                           \
+        _Pragma("unroll") for (int r = 0; r < 8; ++r) {                                 \
+            const f32x2 t = {ubyte_to_float<B>(WA[r]), ubyte_to_float<B>(WB[r])};       \
+            col[r] = t;                                                                 \
+        }                                                                               \
+        pf::dct2_8(col, out);                                                           \
+        _Pragma("unroll") for (int u = 0; u < 8; ++u) V[u][X] = out[u];                 \
+        SVS_SCHED_FENCE();                                                              \
+    }
+        SVS_COL2(0, ax, bx, 0) SVS_COL2(1, ax, bx, 1) SVS_COL2(2, ax, bx, 2) SVS_COL2(3, ax, bx, 3)
+        SVS_COL2(4, ay, by, 0) SVS_COL2(5, ay, by, 1) SVS_COL2(6, ay, by, 2) SVS_COL2(7, ay, by, 3)
+#undef SVS_COL2
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            pf::dct2_8(V[u], D[u]);
+            SVS_SCHED_FENCE();
+        }
+    }
+#pragma unroll
+    for (int k = 1; k < 8 * U; ++k) {
+        if ((uint32_t)k <= n) {  // wave-uniform
+            const int i = k - 1;
+#pragma unroll
+            for (int which = 0; which < 2; ++which) {
+                const int bit = (int)window_bit(which ? hi_b : hi_a, which ? lo_b : lo_a, i);
+                const float c = D[k >> 3][k & 7][which];
+                int q = quant_index<QM>(c, qp);
+                q += bit - (q & 1);
+                float cn;
+                if constexpr (QM == QM_DOUBLE) cn = (float)((double)q * qp.delta_d);
+                else cn = (float)q * qp.delta_f;
+                D[k >> 3][k & 7][which] = ((uint32_t)i < (which ? nb_b : nb_a)) ? cn : c;
+            }
+        }
+    }
+    f32x2 P[8][8];  // after the vertical inverse (axis 0 first, :168): P[y][v]
+#pragma unroll
+    for (int v = 0; v < 8; ++v) {
+        f32x2 col[8], out[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) col[u] = D[u][v];
+        pf::dct3_8(col, out);
+#pragma unroll
+        for (int y = 0; y < 8; ++y) P[y][v] = out[y];
+        SVS_SCHED_FENCE();
+    }
+#pragma unroll
+    for (int y = 0; y < 8; ++y) {
+        f32x2 px[8];
+        pf::dct3_8(P[y], px);
+        // np.uint8(np.clip(v, 0, 255)): floor == trunc on the clipped range, the store saturates
+#pragma unroll
+        for (int which = 0; which < 2; ++which) {
+            uint32_t lo4 = 0, hi4 = 0;
+            lo4 = put_pixel<0>(floorf(px[0][which]), lo4);
+            lo4 = put_pixel<1>(floorf(px[1][which]), lo4);
+            lo4 = put_pixel<2>(floorf(px[2][which]), lo4);
+            lo4 = put_pixel<3>(floorf(px[3][which]), lo4);
+            hi4 = put_pixel<0>(floorf(px[4][which]), hi4);
+            hi4 = put_pixel<1>(floorf(px[5][which]), hi4);
+            hi4 = put_pixel<2>(floorf(px[6][which]), hi4);
+            hi4 = put_pixel<3>(floorf(px[7][which]), hi4);
+            if (which) { bx[y] = lo4; by[y] = hi4; } else { ax[y] = lo4; ay[y] = hi4; }
+        }
+        SVS_SCHED_FENCE();
     }
 }
 

@@ -8,7 +8,10 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <string>
+#include <utility>
 
 namespace {
 
@@ -128,7 +131,7 @@ Tuning embed_tuning(int rows, const svs_planes *p, const void *a, const void *b)
 
 Tuning extract_tuning(int rows, const svs_planes *p, const void *a) {
     Tuning t{false, rows == 1 ? 32u : kEighth};
-    t.two_blocks = rows == 1 && env_chunk("SVS_EXTRACT_BPL", 1) == 2;
+    t.two_blocks = rows <= 2 && env_chunk("SVS_EXTRACT_BPL", 1) == 2;
     t.chunk = env_chunk("SVS_EXTRACT_XCD_CHUNK", t.chunk);
     t.two_blocks = t.two_blocks && rows_allow_two_blocks(p, a, nullptr);
     return t;
@@ -176,7 +179,7 @@ int launch_embed(int rows, uint64_t total, hipStream_t st, const uint8_t *gray, 
 // second pass of a FAST embed: redo the blocks marked in the replay map with the exact arithmetic (svs_device.hpp)
 int launch_embed_replay(int qm, hipStream_t st, const uint8_t *gray, uint8_t *stego, const svs::Geometry &g,
                         const svs::QimParams &qp, const uint32_t *bits, uint64_t bit_offset, uint64_t n_bits,
-                        uint32_t n_words, const uint64_t *replay_map, uint64_t map_words, int bpl) {
+                        uint32_t n_words, uint64_t *replay_map, uint64_t map_words, int bpl) {
     const dim3 grid((uint32_t)((map_words + SVS_WG - 1) / SVS_WG));
 #define SVS_GO(QM)                                                                                                     \
     hipLaunchKernelGGL((svs::embed_replay_kernel<QM>), grid, dim3(SVS_WG), 0, st, gray, stego, g, qp, bits, bit_offset, \
@@ -189,20 +192,52 @@ int launch_embed_replay(int qm, hipStream_t st, const uint8_t *gray, uint8_t *st
     return SVS_OK;
 }
 
-// Stream-ordered scratch for the replay map: allocated and released on the caller's stream, so concurrent embeds on
-// different streams never share it and nothing synchronises.
-struct StreamScratch {
-    void *p = nullptr;
-    hipStream_t st = nullptr;
-    int alloc(size_t bytes, hipStream_t stream) {
-        st = stream;
-        SVS_HIP(hipMallocAsync(&p, bytes, st));
-        return SVS_OK;
-    }
-    ~StreamScratch() {
-        if (p) (void)hipFreeAsync(p, st);
-    }
+// The replay map of a stream (svs_device.hpp "REPLAY MAP"): owned by the library, one per (device, stream), grown on
+// demand, zeroed when allocated and kept all-zero between calls by embed_replay_kernel.  Work on one stream is ordered, so
+// calls on the same stream share it safely; different streams have different maps.
+struct ReplayMap {
+    uint64_t *p = nullptr;
+    size_t words = 0;
 };
+std::mutex g_maps_mutex;
+std::map<std::pair<int, hipStream_t>, ReplayMap> g_maps;
+
+int replay_map_for(hipStream_t st, uint64_t words, uint64_t **out) {
+    int dev = 0;
+    SVS_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(g_maps_mutex);
+    ReplayMap &m = g_maps[std::make_pair(dev, st)];
+    if (m.words < words) {
+        if (m.p) {
+            SVS_HIP(hipStreamSynchronize(st));   // nothing may still be using the old one
+            (void)hipFree(m.p);
+            m = ReplayMap();
+        }
+        const size_t want = (size_t)(words + words / 4 + 1024);
+        void *p = nullptr;
+        SVS_HIP(hipMalloc(&p, want * sizeof(uint64_t)));
+        if (hipMemsetAsync(p, 0, want * sizeof(uint64_t), st) != hipSuccess) {
+            (void)hipFree(p);
+            return fail(SVS_ERR_HIP, "hipMemsetAsync of the replay map failed");
+        }
+        m.p = reinterpret_cast<uint64_t *>(p);
+        m.words = want;
+    }
+    *out = m.p;
+    return SVS_OK;
+}
+
+// after a failed launch the map may hold stale bits: drop it, the next call gets a fresh zeroed one
+void replay_map_discard(hipStream_t st) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return;
+    std::lock_guard<std::mutex> lock(g_maps_mutex);
+    auto it = g_maps.find(std::make_pair(dev, st));
+    if (it == g_maps.end()) return;
+    (void)hipStreamSynchronize(st);
+    (void)hipFree(it->second.p);
+    g_maps.erase(it);
+}
 
 template <int QM, int BPL>
 int launch_extract(int rows, uint64_t total, hipStream_t st, const uint8_t *gray, const svs::Geometry &g,
@@ -213,20 +248,18 @@ int launch_extract(int rows, uint64_t total, hipStream_t st, const uint8_t *gray
     // 600 x 4K, n = 10) and n = 3 gains nothing (HBM-bound), so those stay on the run-time-n kernels.
     const bool fixed_n = env_chunk("SVS_FIXED_N", 1) != 0;   // experiment knob
     const uint32_t lds_pad = lds_pad_for(env_chunk("SVS_EXTRACT_WG_PER_CU", extract_wg_per_cu(rows)), 4096);
-    if constexpr (BPL == 1) {
-        if (fixed_n && g.n_ac == 10) {
-            hipLaunchKernelGGL((svs::extract_kernel<2, QM, 1, 10>), grid, dim3(SVS_WG), lds_pad, st, gray, g, qp, out, out_bytes);
-            SVS_HIP(hipGetLastError());
-            return SVS_OK;
-        }
+    if (fixed_n && g.n_ac == 10) {
+        hipLaunchKernelGGL((svs::extract_kernel<2, QM, BPL, 10>), grid, dim3(SVS_WG), lds_pad, st, gray, g, qp, out, out_bytes);
+        SVS_HIP(hipGetLastError());
+        return SVS_OK;
     }
 #define SVS_CASE(R)                                                                                                  \
     case R:                                                                                                          \
         hipLaunchKernelGGL((svs::extract_kernel<R, QM, BPL>), grid, dim3(SVS_WG), lds_pad, st, gray, g, qp, out, out_bytes); \
         break;
-    if constexpr (BPL == 2) {  // two blocks per lane is only instantiated (and only pays) for one coefficient row
+    if constexpr (BPL == 2) {  // two blocks per lane is only instantiated for one or two coefficient rows
         switch (rows) {
-            SVS_CASE(1)
+            SVS_CASE(1) SVS_CASE(2)
             default: return fail(SVS_ERR_INVALID_ARG, "internal: rows=%d with two blocks per lane", rows);
         }
     } else {
@@ -242,12 +275,33 @@ int launch_extract(int rows, uint64_t total, hipStream_t st, const uint8_t *gray
 
 int launch_embed_exact(int qm, uint64_t total, hipStream_t st, const uint8_t *gray, uint8_t *stego,
                        const svs::Geometry &g, const svs::QimParams &qp, const uint32_t *bits, uint64_t bit_offset,
-                       uint64_t n_bits, uint32_t n_words) {
-    const dim3 grid((uint32_t)((total + SVS_WG - 1) / SVS_WG));
+                       uint64_t n_bits, uint32_t n_words, bool pair = false) {
     const uint32_t lds_pad = lds_pad_for(env_chunk("SVS_EMBED_WG_PER_CU", 0), 0);
     // the kernel's quantiser loop is instantiated for one or two coefficient rows (n <= 7: the benchmark's 3; n <= 15: the
     // reference GUI's 10) and for all eight (any n): fewer wave-uniform tests per block, same arithmetic
     const int rows = rows_for((int)g.n_ac);
+    if (pair) {   // two adjacent blocks per lane, transforms packed over the pair (embed_exact_pair_kernel)
+        const dim3 grid2((uint32_t)((total + 2 * SVS_WG - 1) / (2 * SVS_WG)));
+#define SVS_GO2(QM)                                                                                                         \
+    do {                                                                                                                    \
+        if (rows == 1 && g.n_ac > 0)                                                                                        \
+            hipLaunchKernelGGL((svs::embed_exact_pair_kernel<QM, 1>), grid2, dim3(SVS_WG), lds_pad, st, gray, stego, g, qp, bits, \
+                               bit_offset, n_bits, n_words);                                                                \
+        else if (rows == 2)                                                                                                 \
+            hipLaunchKernelGGL((svs::embed_exact_pair_kernel<QM, 2>), grid2, dim3(SVS_WG), lds_pad, st, gray, stego, g, qp, bits, \
+                               bit_offset, n_bits, n_words);                                                                \
+        else                                                                                                                \
+            hipLaunchKernelGGL((svs::embed_exact_pair_kernel<QM, 8>), grid2, dim3(SVS_WG), lds_pad, st, gray, stego, g, qp, bits, \
+                               bit_offset, n_bits, n_words);                                                                \
+    } while (0)
+        if (qm == svs::QM_DOUBLE) SVS_GO2(svs::QM_DOUBLE);
+        else if (qm == svs::QM_POW2) SVS_GO2(svs::QM_POW2);
+        else SVS_GO2(svs::QM_F32);
+#undef SVS_GO2
+        SVS_HIP(hipGetLastError());
+        return SVS_OK;
+    }
+    const dim3 grid((uint32_t)((total + SVS_WG - 1) / SVS_WG));
 #define SVS_GO(QM)                                                                                                          \
     do {                                                                                                                    \
         if (rows == 1 && g.n_ac > 0)                                                                                        \
@@ -400,6 +454,7 @@ int svs_stream_create(void **stream) {
 }
 
 int svs_stream_destroy(void *stream) {
+    replay_map_discard((hipStream_t)stream);   // the stream's replay map goes with it
     SVS_HIP(hipStreamDestroy((hipStream_t)stream));
     return SVS_OK;
 }
@@ -450,6 +505,11 @@ int svs_embed_dev(const uint8_t *d_gray, uint8_t *d_stego, const svs_planes *pla
     svs::QimParams qp;
     const int qm = make_qim(use == 0 ? 1.0 : delta, &qp);
     if (flags & ~SVS_EXACT_POCKETFFT) return fail(SVS_ERR_INVALID_ARG, "unknown flags 0x%x", flags);
+    // SVS_EXACT_BPL=2 (experiment knob): exact arithmetic on two adjacent blocks per lane with every transform instruction
+    // packed over the pair (embed_exact_pair_kernel).  Measured SLOWER than the one-block kernel (3.54 vs 3.16 ms at n = 3,
+    // 4.83 vs 3.38 ms at n = 10, profiles/r02_ab_exact_pair.txt): a v_pk_*_f32 costs two issue slots on this chip, so
+    // halving the instruction count buys nothing and the 256-register footprint costs occupancy.  Off by default.
+    const bool exact_pair = rows_allow_two_blocks(planes, d_gray, d_stego) && env_chunk("SVS_EXACT_BPL", 1) == 2;
     if (flags & SVS_EXACT_POCKETFFT) {
         g.xcd_chunk = env_chunk("SVS_EMBED_XCD_CHUNK", kEighth);
         if (use == 0) {
@@ -460,13 +520,13 @@ int svs_embed_dev(const uint8_t *d_gray, uint8_t *d_stego, const svs_planes *pla
             }
             // delta <= 0 or no coefficients: nothing is consumed, so every block is entered and round-tripped
             g.n_ac = 0;
-            return launch_embed_exact(svs::QM_F32, total, st, d_gray, d_stego, g, qp, nullptr, 0, 1, 0);
+            return launch_embed_exact(svs::QM_F32, total, st, d_gray, d_stego, g, qp, nullptr, 0, 1, 0, exact_pair);
         }
         const uint64_t words_x = ((bit_offset + use + 7) / 8 + 3) / 4;
         if (words_x >= (1ull << 32)) return fail(SVS_ERR_INVALID_ARG, "payload too large for one call");
         if (int rc = launch_embed_exact(qm, total, st, d_gray, d_stego, g, qp,
                                         reinterpret_cast<const uint32_t *>(d_bits_packed), bit_offset, use,
-                                        (uint32_t)words_x))
+                                        (uint32_t)words_x, exact_pair))
             return rc;
         if (n_embedded) *n_embedded = use;
         return SVS_OK;
@@ -478,7 +538,7 @@ int svs_embed_dev(const uint8_t *d_gray, uint8_t *d_stego, const svs_planes *pla
             // reproduces what that does to the pixels, so FAST takes that kernel here
             g.xcd_chunk = env_chunk("SVS_EMBED_XCD_CHUNK", kEighth);
             g.n_ac = 0;
-            return launch_embed_exact(svs::QM_F32, total, st, d_gray, d_stego, g, qp, nullptr, 0, 1, 0);
+            return launch_embed_exact(svs::QM_F32, total, st, d_gray, d_stego, g, qp, nullptr, 0, 1, 0, exact_pair);
         }
         // empty payload: pure copy, every block is "past the budget"
         if (d_gray == d_stego) return SVS_OK;
@@ -494,9 +554,8 @@ int svs_embed_dev(const uint8_t *d_gray, uint8_t *d_stego, const svs_planes *pla
     // replay map: which blocks the fast kernel leaves to the exact arithmetic (svs_device.hpp "REPLAY MAP")
     const int bpl = two ? 2 : 1;
     const uint64_t map_words = replay_map_words(total, bpl);
-    StreamScratch map;
-    if (int rc = map.alloc(map_words * sizeof(uint64_t), st)) return rc;
-    uint64_t *d_map = reinterpret_cast<uint64_t *>(map.p);
+    uint64_t *d_map = nullptr;
+    if (int rc = replay_map_for(st, map_words, &d_map)) return rc;
     int rc;
 #define SVS_GO(QM)                                                                                                          \
     rc = two ? launch_embed<QM, 2>(rows, total, st, d_gray, d_stego, g, qp, bw, bit_offset, use, (uint32_t)words, d_map)   \
@@ -505,10 +564,12 @@ int svs_embed_dev(const uint8_t *d_gray, uint8_t *d_stego, const svs_planes *pla
     else if (qm == svs::QM_POW2) SVS_GO(svs::QM_POW2);
     else SVS_GO(svs::QM_F32);
 #undef SVS_GO
-    if (rc) return rc;
-    if (int rc2 = launch_embed_replay(qm, st, d_gray, d_stego, g, qp, bw, bit_offset, use, (uint32_t)words, d_map, map_words,
-                                      bpl))
-        return rc2;
+    if (!rc)
+        rc = launch_embed_replay(qm, st, d_gray, d_stego, g, qp, bw, bit_offset, use, (uint32_t)words, d_map, map_words, bpl);
+    if (rc) {
+        replay_map_discard(st);
+        return rc;
+    }
     if (n_embedded) *n_embedded = use;
     return SVS_OK;
 }
@@ -747,10 +808,9 @@ int svs_embed_bgr_dev(const uint8_t *d_bgr_in, int64_t in_row_pitch, int64_t in_
     const int rows = rows_for((int)g.n_ac);
     const bool replay = !exact && use > 0;   // FAST with something to embed: second pass over the replay map
     const uint64_t map_words = replay_map_words(total, 1);
-    StreamScratch map;
+    uint64_t *d_map = nullptr;
     if (replay)
-        if (int rc = map.alloc(map_words * sizeof(uint64_t), st)) return rc;
-    uint64_t *d_map = reinterpret_cast<uint64_t *>(map.p);
+        if (int rc = replay_map_for(st, map_words, &d_map)) return rc;
     int rc;
 #define SVS_GO(QM)                                                                                                       \
     rc = exact ? launch_embed_bgr<QM, true>(rows, total, st, d_bgr_in, d_bgr_out, d_gray_ref, g, c, qp, bw, bit_offset,   \
@@ -767,7 +827,10 @@ int svs_embed_bgr_dev(const uint8_t *d_bgr_in, int64_t in_row_pitch, int64_t in_
     else if (qm == svs::QM_POW2) { SVS_GO(svs::QM_POW2) }
     else { SVS_GO(svs::QM_F32) }
 #undef SVS_GO
-    if (rc) return rc;
+    if (rc) {
+        if (replay) replay_map_discard(st);
+        return rc;
+    }
     if (n_embedded) *n_embedded = use;
     return SVS_OK;
 }

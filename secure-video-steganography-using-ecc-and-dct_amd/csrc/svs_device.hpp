@@ -128,10 +128,11 @@ __device__ __forceinline__ void store_rows(uint8_t *dst, int64_t row_pitch, cons
 //
 // REPLAY MAP.  A block whose change is structurally zero (svs::embed_block returns true) must come out of the
 // pocketfft-identical arithmetic instead - 2 000 VALU operations and 140 VGPRs that this kernel cannot afford inline.
-// Such a block is left as it was (not stored), and the wave publishes which of its blocks those are: one 64-bit ballot
-// word per wave and block-of-the-lane, replay_map[(tile * waves_per_workgroup + wave) * BPL + which], bit = lane.
-// Every wave of the grid writes its words (zeros included), so the map needs no clearing.  embed_replay_kernel then
-// redoes exactly those blocks.  On noise-like content the map is all zeros and the second launch is one read of it.
+// Such a block is left as it was (not stored) and its lane sets one bit in the replay map: 64-bit word
+// (tile * waves_per_workgroup + wave) * BPL + which-block-of-the-lane, bit = lane (a global atomic OR, issued by flagged
+// lanes only).  embed_replay_kernel then redoes exactly those blocks and clears the words it consumed, so the map - a
+// per-stream buffer owned by the library, zeroed when it is allocated - is all zeros again between calls.  On noise-like
+// content nothing is ever flagged: this kernel does not touch the map and the second launch is one read of it.
 template <int U, int QM, int BPL, int NFIX = 0>
 __global__ __launch_bounds__(SVS_WG, (U == 2 ? SVS_U2_MIN_WAVES : 1)) void embed_kernel(const uint8_t *gray,
                                                     uint8_t *stego, const Geometry g,
@@ -192,14 +193,13 @@ __global__ __launch_bounds__(SVS_WG, (U == 2 ? SVS_U2_MIN_WAVES : 1)) void embed
             }
         }
     }
-    if (replay_map != nullptr) {  // kernel argument: uniform
-        const uint64_t ma = __ballot(replay_a);
-        uint64_t *slot = replay_map + ((uint64_t)tile * (SVS_WG / 64) + (threadIdx.x >> 6)) * BPL;
+    if (replay_a | replay_b) {  // rare; replay_map is non-null whenever a block can be entered
+        unsigned long long *slot = reinterpret_cast<unsigned long long *>(replay_map) +
+                                   ((uint64_t)tile * (SVS_WG / 64) + (threadIdx.x >> 6)) * BPL;
+        const unsigned long long bit = 1ull << (threadIdx.x & 63u);
+        if (replay_a) atomicOr(slot, bit);
         if constexpr (BPL == 2) {
-            const uint64_t mb = __ballot(replay_b);
-            if ((threadIdx.x & 63u) == 0) { slot[0] = ma; slot[1] = mb; }
-        } else {
-            if ((threadIdx.x & 63u) == 0) slot[0] = ma;
+            if (replay_b) atomicOr(slot + 1, bit);
         }
     }
 }
@@ -433,6 +433,54 @@ __global__ __launch_bounds__(SVS_WG, SVS_EXACT_MIN_WAVES) void embed_exact_kerne
     store_rows<1>(stego + off, g.row_pitch, v);
 }
 
+// EXACT embed, two adjacent blocks per lane (16-byte row accesses; needs an even number of blocks per row and 16-byte
+// aligned rows - the host checks): the transforms run as packed-FP32 instructions over the pair (svs_block.hpp,
+// embed_block_exact_pair).  Only the lane in which the payload budget ends can have its second block not entered; that
+// block is then copied, not round-tripped (:130,:132).
+#ifndef SVS_EXACT2_MIN_WAVES
+#define SVS_EXACT2_MIN_WAVES 2
+#endif
+template <int QM, int U>
+__global__ __launch_bounds__(SVS_WG, SVS_EXACT2_MIN_WAVES) void embed_exact_pair_kernel(const uint8_t *gray,  // may alias stego
+                                                          uint8_t *stego, const Geometry g, const QimParams qp,
+                                                          const uint32_t *__restrict__ bits, const uint64_t bit_offset,
+                                                          const uint64_t n_bits, const uint32_t n_words) {
+    const uint32_t gblock = (tile_id(g.xcd_chunk) * (uint32_t)SVS_WG + threadIdx.x) * 2u;
+    if (gblock >= g.total_blocks) return;
+    const int64_t off = block_offset(gblock, g);
+    typename RowVec<2>::type v[8];
+    load_rows<2>(gray + off, g.row_pitch, v);
+    const uint32_t n = g.n_ac;  // 0 = round-trip every block without touching a coefficient
+    const uint64_t first = (uint64_t)gblock * n;
+    if (first >= n_bits) {
+        if (stego != gray) store_rows<2>(stego + off, g.row_pitch, v);
+        return;
+    }
+    const bool b_entered = first + n < n_bits || n == 0;   // n == 0: every block is entered (n_bits = 1 then)
+    uint32_t ax[8], ay[8], bx[8], by[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) { ax[r] = v[r].x; ay[r] = v[r].y; bx[r] = v[r].z; by[r] = v[r].w; }
+    uint32_t hi_a, lo_a, hi_b, lo_b;
+    payload_window(bits, n_words, bit_offset + first, hi_a, lo_a);
+    payload_window(bits, n_words, bit_offset + first + n, hi_b, lo_b);
+    embed_block_exact_pair<U, QM>(ax, ay, bx, by, n, block_budget(first, n_bits, n), block_budget(first + n, n_bits, n), hi_a,
+                                  lo_a, hi_b, lo_b, qp);
+    if (b_entered) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) { v[r].x = ax[r]; v[r].y = ay[r]; v[r].z = bx[r]; v[r].w = by[r]; }
+        store_rows<2>(stego + off, g.row_pitch, v);
+    } else {  // the one lane the budget ends in: A is stored, B keeps (or gets a copy of) its original bytes
+        typename RowVec<1>::type h[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) { h[r].x = ax[r]; h[r].y = ay[r]; }
+        store_rows<1>(stego + off, g.row_pitch, h);
+        if (stego != gray) {
+            load_rows<1>(gray + off + 8, g.row_pitch, h);
+            store_rows<1>(stego + off + 8, g.row_pitch, h);
+        }
+    }
+}
+
 // Second pass of FAST embedding: the blocks embed_kernel marked in the replay map are redone with the exact arithmetic,
 // read from `gray` (embed_kernel left them untouched, also when embedding in place) and written to `stego`.  One lane per
 // map word; a lane walks the set bits of its word.  With an all-zero map this is a read of total_blocks / 8 bytes.
@@ -441,11 +489,13 @@ __global__ __launch_bounds__(SVS_WG, SVS_EXACT_MIN_WAVES) void embed_replay_kern
                                                           const Geometry g, const QimParams qp,
                                                           const uint32_t *__restrict__ bits, const uint64_t bit_offset,
                                                           const uint64_t n_bits, const uint32_t n_words,
-                                                          const uint64_t *__restrict__ replay_map,
+                                                          uint64_t *__restrict__ replay_map,
                                                           const uint32_t map_words, const uint32_t bpl) {
     const uint32_t word = blockIdx.x * (uint32_t)SVS_WG + threadIdx.x;
     if (word >= map_words) return;
     uint64_t todo = replay_map[word];
+    if (todo == 0) return;
+    replay_map[word] = 0;  // the map is all zeros again when this kernel has finished
     const uint32_t n = g.n_ac;
     while (todo != 0) {
         const uint32_t bit = (uint32_t)__builtin_ctzll(todo);
@@ -854,9 +904,9 @@ __global__ __launch_bounds__(SVS_WG) void embed_bgr_kernel(const uint8_t *bgr_in
             else replay = embed_block<U, QM>(ax, ay, n, block_budget(first, n_bits, n), hi, lo, qp);
         }
     }
-    const uint64_t skip = EXACT ? 0ull : __ballot(replay);
+    const uint64_t skip = EXACT ? 0ull : __ballot(replay);   // the cooperative store below needs the wave's mask anyway
     if constexpr (!EXACT) {
-        if (replay_map != nullptr && (threadIdx.x & 63u) == 0)
+        if (skip != 0 && (threadIdx.x & 63u) == 0)           // rare; one wave owns the word: a plain store will do
             replay_map[(uint64_t)tile * (SVS_WG / 64) + (threadIdx.x >> 6)] = skip;
     }
 #if defined(SVS_BGR_DIRECT_STORE)
@@ -881,11 +931,13 @@ __global__ __launch_bounds__(SVS_WG, SVS_EXACT_MIN_WAVES) void embed_bgr_replay_
                                                           const Geometry g, const ColourParams c, const QimParams qp,
                                                           const uint32_t *__restrict__ bits, const uint64_t bit_offset,
                                                           const uint64_t n_bits, const uint32_t n_words,
-                                                          const uint64_t *__restrict__ replay_map,
+                                                          uint64_t *__restrict__ replay_map,
                                                           const uint32_t map_words) {
     const uint32_t word = blockIdx.x * (uint32_t)SVS_WG + threadIdx.x;
     if (word >= map_words) return;
     uint64_t todo = replay_map[word];
+    if (todo == 0) return;
+    replay_map[word] = 0;
     const uint32_t n = g.n_ac;
     while (todo != 0) {
         const uint32_t bit = (uint32_t)__builtin_ctzll(todo);

@@ -53,6 +53,14 @@ bool embed_dispatch(int rows, Blk &raw, uint32_t n, uint32_t nb, uint32_t hi, ui
     }
 }
 
+// two adjacent blocks through the packed pair form (what embed_exact_pair_kernel runs)
+void embed_exact_pair_dispatch(Blk &a, Blk &b, uint32_t n, uint32_t nb_a, uint32_t nb_b, uint32_t hi_a, uint32_t lo_a,
+                               uint32_t hi_b, uint32_t lo_b, const svs::QimParams &qp, int qm) {
+    if (qm == svs::QM_DOUBLE) svs::embed_block_exact_pair<8, svs::QM_DOUBLE>(a.x, a.y, b.x, b.y, n, nb_a, nb_b, hi_a, lo_a, hi_b, lo_b, qp);
+    else if (qm == svs::QM_POW2) svs::embed_block_exact_pair<8, svs::QM_POW2>(a.x, a.y, b.x, b.y, n, nb_a, nb_b, hi_a, lo_a, hi_b, lo_b, qp);
+    else svs::embed_block_exact_pair<8, svs::QM_F32>(a.x, a.y, b.x, b.y, n, nb_a, nb_b, hi_a, lo_a, hi_b, lo_b, qp);
+}
+
 void embed_exact_dispatch(Blk &raw, uint32_t n, uint32_t nb, uint32_t hi, uint32_t lo, const svs::QimParams &qp, int qm) {
     if (qm == svs::QM_DOUBLE) svs::embed_block_exact<8, svs::QM_DOUBLE>(raw.x, raw.y, n, nb, hi, lo, qp);
     else if (qm == svs::QM_POW2) svs::embed_block_exact<8, svs::QM_POW2>(raw.x, raw.y, n, nb, hi, lo, qp);
@@ -124,6 +132,19 @@ uint64_t emu_embed(const uint8_t *gray, uint8_t *stego, int F, int H, int W, dou
         raw.load(p, (size_t)W);
         uint32_t hi, lo;
         svs::payload_window(reinterpret_cast<const uint32_t *>(bits), n_words, bit_offset + first, hi, lo);
+        if (exact == 2 && (W / 8) % 2 == 0 && gb % 2 == 0 && svs::block_budget(first + n, use, (uint32_t)n) > 0) {
+            // exact == 2: even/odd block pairs through the packed pair form, as embed_exact_pair_kernel does
+            Blk other;
+            other.load(p + 8, (size_t)W);
+            uint32_t hi_b, lo_b;
+            svs::payload_window(reinterpret_cast<const uint32_t *>(bits), n_words, bit_offset + first + n, hi_b, lo_b);
+            embed_exact_pair_dispatch(raw, other, (uint32_t)n, nb, svs::block_budget(first + n, use, (uint32_t)n), hi, lo, hi_b,
+                                      lo_b, qp, dbl);
+            raw.store(p, (size_t)W);
+            other.store(p + 8, (size_t)W);
+            ++gb;
+            continue;
+        }
         if (!exact) {
             // FAST: blocks whose change is structurally zero are replayed with the exact arithmetic (the kernels do that in
             // a second pass over a per-block bitmap; csrc/svs_device.hpp "replay")

@@ -61,3 +61,25 @@ def test_larger_random_frames_against_oracle():
         _, want, want_used = orc.frame_embed(gray, delta, bits, n_ac)
         assert used == want_used and np.array_equal(stego[0], want)
         assert np.array_equal(emu_extract(gray, delta, n_ac, exact=True), orc.frame_extract_bits(gray, delta, n_ac))
+
+
+def test_pair_form_equals_the_one_block_form(golden):
+    """embed_block_exact_pair (two adjacent blocks per lane, every transform instruction packed over the pair - what
+    embed_exact_pair_kernel runs) gives the bytes of embed_block_exact on every golden case, on partial budgets that end
+    inside the first or the second block of a pair, and on random frames."""
+    arrays, meta = golden
+    for name in single_frame_cases(meta):
+        info, gray, payload = case_inputs(arrays, meta, name)
+        if (gray.shape[1] // 8) % 2:
+            continue
+        a, ua = emu_embed(gray, info["delta"], info["n_ac"], payload, exact=2)
+        assert ua == info["used"] and sha(a[0]) == info["stego_sha256"], name
+    rng = np.random.default_rng(8)
+    frames = rng.integers(0, 256, (2, 32, 64), dtype=np.uint8)
+    for n_ac, delta in ((3, 8), (10, 20), (63, 4), (7, 0.3)):
+        cap = 2 * 4 * 8 * n_ac
+        for n_bits in (cap, cap - 1, n_ac, n_ac + 1, 2 * n_ac, 2 * n_ac - 1, 5 * n_ac + 2, 0, 1):
+            bits = rng.integers(0, 2, 11 + n_bits).astype(np.uint8)
+            one, u1 = emu_embed(frames, delta, n_ac, bits, bit_offset=11, exact=1)
+            two, u2 = emu_embed(frames, delta, n_ac, bits, bit_offset=11, exact=2)
+            assert u1 == u2 and np.array_equal(one, two), (n_ac, delta, n_bits)

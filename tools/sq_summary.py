@@ -20,3 +20,10 @@ for k in ks:
         print(f"   of wave-cycles: wait_any {m.get('SQ_WAIT_ANY',0)/wc:.2f} wait_inst {m.get('SQ_WAIT_INST_ANY',0)/wc:.2f} active_any {m.get('SQ_ACTIVE_INST_ANY',0)/wc:.2f} active_valu {m.get('SQ_ACTIVE_INST_VALU',0)/wc:.2f}; busy_cycles {m.get('SQ_BUSY_CYCLES',0):.3g}")
     if "GRBM_GUI_ACTIVE" in m:
         print(f"   eff clock {m['GRBM_GUI_ACTIVE']/8/us/1e3:.2f} GHz")
+    if "SQC_ICACHE_REQ" in m:
+        req = max(m["SQC_ICACHE_REQ"], 1)
+        print(f"   instruction cache: requests {m['SQC_ICACHE_REQ']:.3g} ({m['SQC_ICACHE_REQ']/w:.1f} per wave), hits {m.get('SQC_ICACHE_HITS',0)/req:.4f}, "
+              f"misses {m.get('SQC_ICACHE_MISSES',0)/req:.5f}, duplicate misses {m.get('SQC_ICACHE_MISSES_DUPLICATE',0)/req:.5f}")
+    if "SQ_IFETCH" in m:
+        print(f"   instruction fetches per wave {m['SQ_IFETCH']/w:.1f}; mean fetch latency {m.get('SQ_IFETCH_LEVEL',0)/max(m['SQ_IFETCH'],1):.1f} cycles; "
+              f"VALU_CVT per wave {m.get('SQ_INSTS_VALU_CVT',0)/w:.0f}, VALU_INT32 per wave {m.get('SQ_INSTS_VALU_INT32',0)/w:.0f}")
