@@ -129,10 +129,10 @@ __device__ __forceinline__ void store_rows(uint8_t *dst, int64_t row_pitch, cons
 // REPLAY MAP.  A block whose change is structurally zero (svs::embed_block returns true) must come out of the
 // pocketfft-identical arithmetic instead - 2 000 VALU operations and 140 VGPRs that this kernel cannot afford inline.
 // Such a block is left as it was (not stored) and its lane sets one bit in the replay map: 64-bit word
-// (tile * waves_per_workgroup + wave) * BPL + which-block-of-the-lane, bit = lane (a global atomic OR, issued by flagged
-// lanes only).  embed_replay_kernel then redoes exactly those blocks and clears the words it consumed, so the map - a
-// per-stream buffer owned by the library, zeroed when it is allocated - is all zeros again between calls.  On noise-like
-// content nothing is ever flagged: this kernel does not touch the map and the second launch is one read of it.
+// (tile * waves_per_workgroup + wave) * BPL + which-block-of-the-lane, bit = lane.  A wave owns its words and stores its
+// ballot only when it is non-zero.  embed_replay_kernel then redoes exactly those blocks and clears the words it consumed,
+// so the map - a per-stream buffer owned by the library, zeroed when it is allocated - is all zeros again between calls.
+// On noise-like content nothing is ever flagged: this kernel does not touch the map and the second launch is one read of it.
 template <int U, int QM, int BPL, int NFIX = 0>
 __global__ __launch_bounds__(SVS_WG, (U == 2 ? SVS_U2_MIN_WAVES : 1)) void embed_kernel(const uint8_t *gray,
                                                     uint8_t *stego, const Geometry g,
@@ -193,14 +193,14 @@ __global__ __launch_bounds__(SVS_WG, (U == 2 ? SVS_U2_MIN_WAVES : 1)) void embed
             }
         }
     }
-    if (replay_a | replay_b) {  // rare; replay_map is non-null whenever a block can be entered
-        unsigned long long *slot = reinterpret_cast<unsigned long long *>(replay_map) +
-                                   ((uint64_t)tile * (SVS_WG / 64) + (threadIdx.x >> 6)) * BPL;
-        const unsigned long long bit = 1ull << (threadIdx.x & 63u);
-        if (replay_a) atomicOr(slot, bit);
-        if constexpr (BPL == 2) {
-            if (replay_b) atomicOr(slot + 1, bit);
-        }
+    // publication: the wave owns its map word(s), so one lane stores the ballot - and only when it is non-zero (rare;
+    // replay_map is non-null whenever a block can be entered)
+    const uint64_t ma = __ballot(replay_a);
+    const uint64_t mb = BPL == 2 ? __ballot(replay_b) : 0ull;
+    if ((ma | mb) != 0 && (threadIdx.x & 63u) == 0) {
+        uint64_t *slot = replay_map + ((uint64_t)tile * (SVS_WG / 64) + (threadIdx.x >> 6)) * BPL;
+        slot[0] = ma;
+        if constexpr (BPL == 2) slot[1] = mb;
     }
 }
 
@@ -482,8 +482,29 @@ __global__ __launch_bounds__(SVS_WG, SVS_EXACT2_MIN_WAVES) void embed_exact_pair
 }
 
 // Second pass of FAST embedding: the blocks embed_kernel marked in the replay map are redone with the exact arithmetic,
-// read from `gray` (embed_kernel left them untouched, also when embedding in place) and written to `stego`.  One lane per
-// map word; a lane walks the set bits of its word.  With an all-zero map this is a read of total_blocks / 8 bytes.
+// read from `gray` (embed_kernel left them untouched, also when embedding in place) and written to `stego`.
+// A wave reads 64 map words (one per lane) and leaves if all are zero - with an all-zero map the whole pass is a read of
+// total_blocks / 8 bytes.  Otherwise it takes its non-zero words one at a time, the word broadcast to all lanes and lane i
+// redoing the block of bit i: the same lane-per-block mapping, coalescing and balance as embed_exact_kernel, so that
+// content full of flat areas (letterbox bars flag every block they cover) runs at that kernel's speed.  Consumed words
+// are cleared: the map is all zeros again when the pass has finished.
+struct ReplayWork {
+    uint64_t mine;     // this lane's map word
+    uint64_t pending;  // ballot: lanes of the wave whose word is non-zero
+};
+__device__ __forceinline__ ReplayWork replay_fetch(uint64_t *__restrict__ replay_map, uint32_t word, uint32_t map_words) {
+    ReplayWork w;
+    w.mine = word < map_words ? replay_map[word] : 0ull;
+    w.pending = __ballot(w.mine != 0);
+    if (w.mine != 0) replay_map[word] = 0;
+    return w;
+}
+__device__ __forceinline__ uint64_t replay_broadcast(uint64_t v, uint32_t src_lane) {  // src_lane: wave-uniform
+    const uint32_t lo = __builtin_amdgcn_readlane((int)(uint32_t)v, (int)src_lane);
+    const uint32_t hi = __builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), (int)src_lane);
+    return ((uint64_t)hi << 32) | lo;
+}
+
 template <int QM>
 __global__ __launch_bounds__(SVS_WG, SVS_EXACT_MIN_WAVES) void embed_replay_kernel(const uint8_t *gray, uint8_t *stego,
                                                           const Geometry g, const QimParams qp,
@@ -491,16 +512,15 @@ __global__ __launch_bounds__(SVS_WG, SVS_EXACT_MIN_WAVES) void embed_replay_kern
                                                           const uint64_t n_bits, const uint32_t n_words,
                                                           uint64_t *__restrict__ replay_map,
                                                           const uint32_t map_words, const uint32_t bpl) {
-    const uint32_t word = blockIdx.x * (uint32_t)SVS_WG + threadIdx.x;
-    if (word >= map_words) return;
-    uint64_t todo = replay_map[word];
-    if (todo == 0) return;
-    replay_map[word] = 0;  // the map is all zeros again when this kernel has finished
+    const uint32_t word = blockIdx.x * (uint32_t)SVS_WG + threadIdx.x, lane = threadIdx.x & 63u;
+    ReplayWork work = replay_fetch(replay_map, word, map_words);
     const uint32_t n = g.n_ac;
-    while (todo != 0) {
-        const uint32_t bit = (uint32_t)__builtin_ctzll(todo);
-        todo &= todo - 1;
-        const uint32_t gblock = replay_block(word, bit, bpl);
+    while (work.pending != 0) {  // wave-uniform
+        const uint32_t src = (uint32_t)__builtin_ctzll(work.pending);
+        work.pending &= work.pending - 1;
+        const uint64_t todo = replay_broadcast(work.mine, src);
+        if (!((todo >> lane) & 1ull)) continue;
+        const uint32_t gblock = replay_block(word - lane + src, lane, bpl);
         const int64_t off = block_offset(gblock, g);
         typename RowVec<1>::type v[8];
         load_rows<1>(gray + off, g.row_pitch, v);
@@ -925,7 +945,8 @@ __global__ __launch_bounds__(SVS_WG) void embed_bgr_kernel(const uint8_t *bgr_in
 }
 
 // Second pass of the FAST fused colour embed: blocks marked in the replay map are redone from the original BGR pixels
-// with the exact arithmetic (gray reference frame: already written by the first pass).  One lane per map word.
+// with the exact arithmetic (gray reference frame: already written by the first pass); work distribution as in
+// embed_replay_kernel.
 template <int QM>
 __global__ __launch_bounds__(SVS_WG, SVS_EXACT_MIN_WAVES) void embed_bgr_replay_kernel(const uint8_t *bgr_in, uint8_t *bgr_out,
                                                           const Geometry g, const ColourParams c, const QimParams qp,
@@ -933,22 +954,21 @@ __global__ __launch_bounds__(SVS_WG, SVS_EXACT_MIN_WAVES) void embed_bgr_replay_
                                                           const uint64_t n_bits, const uint32_t n_words,
                                                           uint64_t *__restrict__ replay_map,
                                                           const uint32_t map_words) {
-    const uint32_t word = blockIdx.x * (uint32_t)SVS_WG + threadIdx.x;
-    if (word >= map_words) return;
-    uint64_t todo = replay_map[word];
-    if (todo == 0) return;
-    replay_map[word] = 0;
+    const uint32_t word = blockIdx.x * (uint32_t)SVS_WG + threadIdx.x, lane = threadIdx.x & 63u;
+    ReplayWork work = replay_fetch(replay_map, word, map_words);
     const uint32_t n = g.n_ac;
-    while (todo != 0) {
-        const uint32_t bit = (uint32_t)__builtin_ctzll(todo);
-        todo &= todo - 1;
-        const uint32_t gblock = replay_block(word, bit, 1u);
-        const uint8_t *src = bgr_in + block_offset_bgr(gblock, g, c.in_row_pitch, c.in_frame_pitch);
+    while (work.pending != 0) {  // wave-uniform; see embed_replay_kernel
+        const uint32_t src = (uint32_t)__builtin_ctzll(work.pending);
+        work.pending &= work.pending - 1;
+        const uint64_t todo = replay_broadcast(work.mine, src);
+        if (!((todo >> lane) & 1ull)) continue;
+        const uint32_t gblock = replay_block(word - lane + src, lane, 1u);
+        const uint8_t *src_px = bgr_in + block_offset_bgr(gblock, g, c.in_row_pitch, c.in_frame_pitch);
         uint32_t ax[8], ay[8];
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
             u32x2 q0, q1, q2;
-            load_bgr_row(src + r * c.in_row_pitch, q0, q1, q2);
+            load_bgr_row(src_px + r * c.in_row_pitch, q0, q1, q2);
             bgr8_to_gray(q0, q1, q2, c, ax[r], ay[r]);
         }
         const uint64_t first = (uint64_t)gblock * n;
