@@ -51,17 +51,22 @@ extern "C" {
 #define SVS_ERR_CAPACITY (-4)     /* an output buffer is too small */
 
 /* `flags` of the embed / extract entry points.
- *   0                  FAST transforms: an FMA-factored float32 DCT restricted to the coefficient rows the
- *                      payload touches.  Meets the operator's contract - extracted bits bit-exact, stego PSNR
- *                      within 0.01 dB of the reference - and runs on the HBM roofline.  Stego pixels can differ
- *                      from the reference's where float32 noise decides the outcome - a near-tie of c/delta (so can
- *                      bits extracted from frames that were never embedded) or a stego value within ~1e-5 of an
- *                      integer (about 1e-5 of the pixels at n = 3, 1e-3 at n = 10) - and a block that receives no
- *                      coefficient change is left untouched.
+ *   0                  FAST: an FMA-factored float32 DCT restricted to the coefficient rows the payload touches, at
+ *                      HBM-roofline speed, with the two places where float32 noise of the reference's own transform
+ *                      decides the outcome sent through the exact arithmetic below:
+ *                        - embed: a block whose coefficient changes are structurally zero (flat areas, letterbox bars,
+ *                          one-dimensional structure; config_and_setup.py:166-171 round-trips such a block and truncates
+ *                          x - 1e-5 to x - 1) is redone by a second, small launch (embed_replay_kernel);
+ *                        - extract: a block with a quantiser input within a proven error bound of a rounding tie is
+ *                          recomputed inside the kernel with the pocketfft-identical transform.
+ *                      Result: extracted bits identical to the reference's for ANY input frame; stego PSNR within
+ *                      0.01 dB of the reference's on any content (measured <= 0.003 dB, tests/test_gpu_parity.py).
+ *                      Stego pixels can still differ from the reference's where float32 noise decides a single
+ *                      pixel's floor or a quantiser near-tie (about 1e-5 of the pixels at n = 3, 1e-3 at n = 10).
  *   SVS_EXACT_POCKETFFT  every float32 operation of scipy.fftpack.dct/idct(norm='ortho') (pocketfft) is
  *                      replayed in order, on all 64 coefficients: stego pixels, tie decisions and the
- *                      reference's round-trip artefacts (config_and_setup.py:166-171 on untouched blocks) are
- *                      bit-identical to the reference.  About 2.5x the arithmetic: VALU-bound. */
+ *                      reference's round-trip artefacts are bit-identical to the reference.  About 2.5x the
+ *                      arithmetic: VALU-bound. */
 #define SVS_EXACT_POCKETFFT 1u
 
 /* Geometry of a batch of gray planes. */
@@ -114,8 +119,11 @@ uint64_t svs_packed_bytes(uint64_t n_bits);
  *                  Blocks past the budget are copied byte-identically; a block the budget ends
  *                  in has only its first coefficients modified (config_and_setup.py:130,132,141).
  *   n_embedded   : (host) receives min(n_bits, capacity); 0 when delta <= 0 or n_ac <= 0.
- * delta <= 0 or n_ac <= 0: nothing can be embedded.  FAST: stego = gray.  EXACT: as in the reference, every
- * block is still transformed forth and back when n_bits > 0 (config_and_setup.py:143-145,166-169).
+ * delta <= 0 or n_ac <= 0: nothing can be embedded; as in the reference every block is still transformed forth and
+ * back when n_bits > 0 (config_and_setup.py:143-145,166-169) - both modes run the exact arithmetic for that.
+ * Scratch: FAST keeps one small replay map per (device, stream) inside the library (1 bit per block of the largest
+ * batch seen on that stream; released by svs_stream_destroy).  Calls on one stream are ordered; concurrent calls must
+ * use different streams.
  */
 int svs_embed_dev(const uint8_t *d_gray, uint8_t *d_stego, const svs_planes *planes,
                   double delta, int n_ac,
