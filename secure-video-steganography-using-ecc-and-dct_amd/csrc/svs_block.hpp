@@ -173,6 +173,44 @@ SVS_HD uint32_t put_pixel_rne(float v, uint32_t old) {
 #endif
 }
 
+// Eight float pixel values of one row -> their bytes in two dwords: np.uint8(np.clip(v, 0, 255)) of the reference
+// (config_and_setup.py:171), i.e. clip, then truncate toward zero.  On the device this is v_cvt_pk_u8_f32 executed with the
+// wave's FP32 rounding mode switched to round-toward-zero for exactly these eight instructions: the conversion saturates
+// to [0, 255] and follows MODE.fp_round (measured on gfx950 with tools/probes/cvt_round_mode.hip: 126.99999 -> 126,
+// 0.99999994 -> 0, -0.9 -> 0, 255.7 -> 255), which saves the v_floor_f32 per pixel of the floor-then-convert form.  One asm
+// statement, so that no other floating-point instruction can be scheduled into the window.
+SVS_HD void store_row_trunc(float p0, float p1, float p2, float p3, float p4, float p5, float p6, float p7, uint32_t &lo4,
+                            uint32_t &hi4) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(SVS_NO_CVT_PK_U8) && !defined(SVS_NO_RTZ_STORE)
+    uint32_t a, b;
+    asm volatile(
+        "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 3\n\t"
+        "s_nop 0\n\t"
+        "v_cvt_pk_u8_f32 %0, %2, 0, 0\n\t"
+        "v_cvt_pk_u8_f32 %1, %6, 0, 0\n\t"
+        "v_cvt_pk_u8_f32 %0, %3, 1, %0\n\t"
+        "v_cvt_pk_u8_f32 %1, %7, 1, %1\n\t"
+        "v_cvt_pk_u8_f32 %0, %4, 2, %0\n\t"
+        "v_cvt_pk_u8_f32 %1, %8, 2, %1\n\t"
+        "v_cvt_pk_u8_f32 %0, %5, 3, %0\n\t"
+        "v_cvt_pk_u8_f32 %1, %9, 3, %1\n\t"
+        "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 0"
+        : "=&v"(a), "=&v"(b)
+        : "v"(p0), "v"(p1), "v"(p2), "v"(p3), "v"(p4), "v"(p5), "v"(p6), "v"(p7));
+    lo4 = a;
+    hi4 = b;
+#else
+    const float v[8] = {p0, p1, p2, p3, p4, p5, p6, p7};
+    uint32_t w[2] = {0, 0};
+    for (int j = 0; j < 8; ++j) {
+        const float c = v[j] < 0.0f ? 0.0f : (v[j] > 255.0f ? 255.0f : v[j]);   // NaN cannot occur (finite pixels)
+        w[j >> 2] |= (uint32_t)c << (8 * (j & 3));
+    }
+    lo4 = w[0];
+    hi4 = w[1];
+#endif
+}
+
 #ifndef SVS_FLOOR_STORE
 #define SVS_FLOOR_STORE 0  // 1: explicit floor + add + store for every U (experiment / A-B)
 #endif
@@ -765,21 +803,11 @@ SVS_HD void embed_block_exact(uint32_t (&rx)[8], uint32_t (&ry)[8], uint32_t n, 
             in[2 * p2 + 1] = o;
         }
         pf::dct3_8(in, px);
-        // np.uint8(np.clip(v, 0, 255)): floor == trunc on the clipped range, the store saturates
+        // np.uint8(np.clip(v, 0, 255)): clip, then truncate (every byte is overwritten: the input rows are dead)
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            uint32_t lo4 = 0, hi4 = 0;  // every byte is overwritten: the input rows are dead after the forward pass
-            lo4 = put_pixel<0>(floorf(px[0][k]), lo4);
-            lo4 = put_pixel<1>(floorf(px[1][k]), lo4);
-            lo4 = put_pixel<2>(floorf(px[2][k]), lo4);
-            lo4 = put_pixel<3>(floorf(px[3][k]), lo4);
-            hi4 = put_pixel<0>(floorf(px[4][k]), hi4);
-            hi4 = put_pixel<1>(floorf(px[5][k]), hi4);
-            hi4 = put_pixel<2>(floorf(px[6][k]), hi4);
-            hi4 = put_pixel<3>(floorf(px[7][k]), hi4);
-            rx[2 * q + k] = lo4;
-            ry[2 * q + k] = hi4;
-        }
+        for (int k = 0; k < 2; ++k)
+            store_row_trunc(px[0][k], px[1][k], px[2][k], px[3][k], px[4][k], px[5][k], px[6][k], px[7][k], rx[2 * q + k],
+                            ry[2 * q + k]);
     }
 }
 
@@ -848,20 +876,9 @@ SVS_HD void embed_block_exact_pair(uint32_t (&ax)[8], uint32_t (&ay)[8], uint32_
     for (int y = 0; y < 8; ++y) {
         f32x2 px[8];
         pf::dct3_8(P[y], px);
-        // np.uint8(np.clip(v, 0, 255)): floor == trunc on the clipped range, the store saturates
-#pragma unroll
-        for (int which = 0; which < 2; ++which) {
-            uint32_t lo4 = 0, hi4 = 0;
-            lo4 = put_pixel<0>(floorf(px[0][which]), lo4);
-            lo4 = put_pixel<1>(floorf(px[1][which]), lo4);
-            lo4 = put_pixel<2>(floorf(px[2][which]), lo4);
-            lo4 = put_pixel<3>(floorf(px[3][which]), lo4);
-            hi4 = put_pixel<0>(floorf(px[4][which]), hi4);
-            hi4 = put_pixel<1>(floorf(px[5][which]), hi4);
-            hi4 = put_pixel<2>(floorf(px[6][which]), hi4);
-            hi4 = put_pixel<3>(floorf(px[7][which]), hi4);
-            if (which) { bx[y] = lo4; by[y] = hi4; } else { ax[y] = lo4; ay[y] = hi4; }
-        }
+        // np.uint8(np.clip(v, 0, 255)): clip, then truncate
+        store_row_trunc(px[0][0], px[1][0], px[2][0], px[3][0], px[4][0], px[5][0], px[6][0], px[7][0], ax[y], ay[y]);
+        store_row_trunc(px[0][1], px[1][1], px[2][1], px[3][1], px[4][1], px[5][1], px[6][1], px[7][1], bx[y], by[y]);
         SVS_SCHED_FENCE();
     }
 }

@@ -644,20 +644,23 @@ int svs_embed(const uint8_t *gray, uint8_t *stego, const svs_planes *planes, dou
     const uint64_t cap = total * (uint64_t)g.n_ac;
     const uint64_t use = n_bits < cap ? n_bits : cap;
     if (use && !bits_packed) return fail(SVS_ERR_INVALID_ARG, "bits pointer is NULL");
-    const uint64_t bit_bytes = use ? (bit_offset + use + 7) / 8 : 0;
+    // only the payload bytes this call reads go to the device: [first_byte, last_byte), first_byte dword aligned, the
+    // bit offset rebased onto it (a frame loop that indexes one long stream by bit_offset stays O(batch) per call)
+    const uint64_t first_byte = use ? (bit_offset / 32) * 4 : 0;
+    const uint64_t bit_bytes = use ? (bit_offset + use + 7) / 8 - first_byte : 0;
     const uint64_t bit_alloc = ((bit_bytes + 3) / 4) * 4 + 4;
     DevBuf d_frames, d_bits;
     SVS_HIP(hipMalloc(&d_frames.p, span));
     SVS_HIP(hipMalloc(&d_bits.p, bit_alloc));
     SVS_HIP(hipMemcpy(d_frames.p, gray, span, hipMemcpyHostToDevice));
     SVS_HIP(hipMemset(d_bits.p, 0, bit_alloc));
-    if (bit_bytes) SVS_HIP(hipMemcpy(d_bits.p, bits_packed, bit_bytes, hipMemcpyHostToDevice));
+    if (bit_bytes) SVS_HIP(hipMemcpy(d_bits.p, bits_packed + first_byte, bit_bytes, hipMemcpyHostToDevice));
     uint64_t done = 0;
     // a non-empty payload that cannot be embedded (delta <= 0, n_ac = 0) must still reach the kernel as
-    // "non-empty": in EXACT mode every block is then round-tripped, as in the reference
+    // "non-empty": every block is then round-tripped, as in the reference
     const uint64_t pass_bits = use ? use : (n_bits ? 1 : 0);
     if (int rc = svs_embed_dev((const uint8_t *)d_frames.p, (uint8_t *)d_frames.p, planes, delta, n_ac,
-                               (const uint8_t *)d_bits.p, bit_offset, pass_bits, flags, &done, nullptr))
+                               (const uint8_t *)d_bits.p, bit_offset - 8 * first_byte, pass_bits, flags, &done, nullptr))
         return rc;
     // copy back pixel bytes only (padding in the caller's stego buffer is left alone)
     if (planes->row_pitch == planes->width && planes->frame_pitch == (int64_t)planes->height * planes->row_pitch) {
@@ -901,7 +904,8 @@ int svs_embed_bgr(const uint8_t *bgr, uint8_t *bgr_out, uint8_t *gray_ref_out, c
     const uint64_t cap = total * (uint64_t)g.n_ac;
     const uint64_t use = n_bits < cap ? n_bits : cap;
     if (use && !bits_packed) return fail(SVS_ERR_INVALID_ARG, "bits pointer is NULL");
-    const uint64_t bit_bytes = use ? (bit_offset + use + 7) / 8 : 0;
+    const uint64_t first_byte = use ? (bit_offset / 32) * 4 : 0;     // see svs_embed
+    const uint64_t bit_bytes = use ? (bit_offset + use + 7) / 8 - first_byte : 0;
     const uint64_t bit_alloc = ((bit_bytes + 3) / 4) * 4 + 4;
     DevBuf d_in, d_out, d_gray, d_bits;
     SVS_HIP(hipMalloc(&d_in.p, 3 * px));
@@ -910,13 +914,13 @@ int svs_embed_bgr(const uint8_t *bgr, uint8_t *bgr_out, uint8_t *gray_ref_out, c
     SVS_HIP(hipMalloc(&d_bits.p, bit_alloc));
     SVS_HIP(hipMemcpy(d_in.p, bgr, 3 * px, hipMemcpyHostToDevice));
     SVS_HIP(hipMemset(d_bits.p, 0, bit_alloc));
-    if (bit_bytes) SVS_HIP(hipMemcpy(d_bits.p, bits_packed, bit_bytes, hipMemcpyHostToDevice));
+    if (bit_bytes) SVS_HIP(hipMemcpy(d_bits.p, bits_packed + first_byte, bit_bytes, hipMemcpyHostToDevice));
     const int64_t rp = 3 * (int64_t)planes->width, fp = rp * planes->height;
     uint64_t done = 0;
     const uint64_t pass_bits = use ? use : (n_bits ? 1 : 0);  // see svs_embed
     if (int rc = svs_embed_bgr_dev((const uint8_t *)d_in.p, rp, fp, (uint8_t *)d_out.p, rp, fp, (uint8_t *)d_gray.p, planes,
-                                   weights, delta, n_ac, (const uint8_t *)d_bits.p, bit_offset, pass_bits, flags, &done,
-                                   nullptr))
+                                   weights, delta, n_ac, (const uint8_t *)d_bits.p, bit_offset - 8 * first_byte, pass_bits,
+                                   flags, &done, nullptr))
         return rc;
     SVS_HIP(hipMemcpy(bgr_out, d_out.p, 3 * px, hipMemcpyDeviceToHost));
     if (gray_ref_out) SVS_HIP(hipMemcpy(gray_ref_out, d_gray.p, px, hipMemcpyDeviceToHost));

@@ -77,6 +77,13 @@ def pack_bits(bits: np.ndarray) -> np.ndarray:
     return packed
 
 
+def _pack_window(bits: np.ndarray, bit_offset: int, n_bits: int):
+    """Pack only the part of a long 0/1 stream one call reads: -> (packed bytes, bit offset rebased onto them).
+    A frame loop that walks one stream by bit offset then packs O(batch) bits per call, not O(stream)."""
+    start = (int(bit_offset) // 32) * 32
+    return pack_bits(bits[start:int(bit_offset) + int(n_bits)]), int(bit_offset) - start
+
+
 def unpack_to_str(packed: np.ndarray, n_bits: int) -> str:
     return bits_to_str(np.unpackbits(np.asarray(packed, np.uint8), count=n_bits))
 
@@ -113,7 +120,7 @@ def embed_frames(frames: np.ndarray, delta, n_ac, bits, bit_offset: int = 0, n_b
         n_bits = max(0, bits.size - bit_offset)
     if bit_offset + n_bits > bits.size:
         raise ValueError("bit_offset + n_bits exceeds the payload length")
-    packed = pack_bits(bits)
+    packed, bit_offset = _pack_window(bits, bit_offset, n_bits)
     stego = np.empty_like(stack)
     done = C.c_uint64(0)
     planes = Planes.contiguous(f, h, w)
@@ -227,7 +234,7 @@ def embed_bgr_frames(frames_bgr: np.ndarray, delta, n_ac, bits, bit_offset: int 
         n_bits = max(0, bits.size - bit_offset)
     if bit_offset + n_bits > bits.size:
         raise ValueError("bit_offset + n_bits exceeds the payload length")
-    packed = pack_bits(bits)
+    packed, bit_offset = _pack_window(bits, bit_offset, n_bits)
     planes = Planes.contiguous(f, h, w)
     out = np.empty_like(stack)
     gray = np.empty((f, h, w), np.uint8) if want_gray else None
