@@ -180,7 +180,7 @@ int launch_embed(int rows, uint64_t total, hipStream_t st, const uint8_t *gray, 
 int launch_embed_replay(int qm, hipStream_t st, const uint8_t *gray, uint8_t *stego, const svs::Geometry &g,
                         const svs::QimParams &qp, const uint32_t *bits, uint64_t bit_offset, uint64_t n_bits,
                         uint32_t n_words, uint64_t *replay_map, uint64_t map_words, int bpl) {
-    const dim3 grid((uint32_t)((map_words + SVS_WG - 1) / SVS_WG));
+    const dim3 grid(svs::replay_grid(map_words));
 #define SVS_GO(QM)                                                                                                     \
     hipLaunchKernelGGL((svs::embed_replay_kernel<QM>), grid, dim3(SVS_WG), 0, st, gray, stego, g, qp, bits, bit_offset, \
                        n_bits, n_words, replay_map, (uint32_t)map_words, (uint32_t)bpl)
@@ -821,7 +821,7 @@ int svs_embed_bgr_dev(const uint8_t *d_bgr_in, int64_t in_row_pitch, int64_t in_
                : launch_embed_bgr<QM, false>(rows, total, st, d_bgr_in, d_bgr_out, d_gray_ref, g, c, qp, bw, bit_offset,  \
                                              kernel_bits, words, d_map);                                                  \
     if (!rc && replay) {                                                                                                 \
-        hipLaunchKernelGGL((svs::embed_bgr_replay_kernel<QM>), dim3((uint32_t)((map_words + SVS_WG - 1) / SVS_WG)),      \
+        hipLaunchKernelGGL((svs::embed_bgr_replay_kernel<QM>), dim3(svs::replay_grid(map_words)),                        \
                            dim3(SVS_WG), 0, st, d_bgr_in, d_bgr_out, g, c, qp, bw, bit_offset, kernel_bits, words, d_map,  \
                            (uint32_t)map_words);                                                                         \
         if (hipGetLastError() != hipSuccess) rc = fail(SVS_ERR_HIP, "embed_bgr_replay_kernel launch failed");            \

@@ -483,21 +483,38 @@ __global__ __launch_bounds__(SVS_WG, SVS_EXACT2_MIN_WAVES) void embed_exact_pair
 
 // Second pass of FAST embedding: the blocks embed_kernel marked in the replay map are redone with the exact arithmetic,
 // read from `gray` (embed_kernel left them untouched, also when embedding in place) and written to `stego`.
-// A wave reads 64 map words (one per lane) and leaves if all are zero - with an all-zero map the whole pass is a read of
-// total_blocks / 8 bytes.  Otherwise it takes its non-zero words one at a time, the word broadcast to all lanes and lane i
+// A wave reads SVS_REPLAY_WORDS map words (one per lane) and leaves if all are zero - with an all-zero map the whole pass is
+// a read of total_blocks / 8 bytes.  Otherwise it takes its non-zero words one at a time, the word broadcast to all lanes and lane i
 // redoing the block of bit i: the same lane-per-block mapping, coalescing and balance as embed_exact_kernel, so that
 // content full of flat areas (letterbox bars flag every block they cover) runs at that kernel's speed.  Consumed words
 // are cleared: the map is all zeros again when the pass has finished.
+// A wave takes SVS_REPLAY_WORDS map words (lanes 0 .. SVS_REPLAY_WORDS-1 fetch one each): fewer words per wave means more
+// waves to share a flat area's blocks (64 words = 4 096 blocks would leave a letterbox bar to a handful of waves running
+// one at a time per SIMD) at the price of more waves to launch when the map is empty.
+#ifndef SVS_REPLAY_WORDS
+#define SVS_REPLAY_WORDS 32
+#endif
 struct ReplayWork {
     uint64_t mine;     // this lane's map word
     uint64_t pending;  // ballot: lanes of the wave whose word is non-zero
+    uint32_t first;    // index of the wave's first map word
 };
-__device__ __forceinline__ ReplayWork replay_fetch(uint64_t *__restrict__ replay_map, uint32_t word, uint32_t map_words) {
+__device__ __forceinline__ ReplayWork replay_fetch(uint64_t *__restrict__ replay_map, uint32_t map_words) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = blockIdx.x * (uint32_t)(SVS_WG / 64) + (threadIdx.x >> 6);
     ReplayWork w;
-    w.mine = word < map_words ? replay_map[word] : 0ull;
+    w.first = wave * (uint32_t)SVS_REPLAY_WORDS;
+    const uint32_t word = w.first + lane;
+    const bool mine = lane < (uint32_t)SVS_REPLAY_WORDS && word < map_words;
+    w.mine = mine ? replay_map[word] : 0ull;
     w.pending = __ballot(w.mine != 0);
     if (w.mine != 0) replay_map[word] = 0;
     return w;
+}
+// workgroups a replay launch needs for `map_words` words
+__host__ __device__ inline uint32_t replay_grid(uint64_t map_words) {
+    const uint64_t per_wg = (uint64_t)(SVS_WG / 64) * SVS_REPLAY_WORDS;
+    return (uint32_t)((map_words + per_wg - 1) / per_wg);
 }
 __device__ __forceinline__ uint64_t replay_broadcast(uint64_t v, uint32_t src_lane) {  // src_lane: wave-uniform
     const uint32_t lo = __builtin_amdgcn_readlane((int)(uint32_t)v, (int)src_lane);
@@ -512,15 +529,15 @@ __global__ __launch_bounds__(SVS_WG, SVS_EXACT_MIN_WAVES) void embed_replay_kern
                                                           const uint64_t n_bits, const uint32_t n_words,
                                                           uint64_t *__restrict__ replay_map,
                                                           const uint32_t map_words, const uint32_t bpl) {
-    const uint32_t word = blockIdx.x * (uint32_t)SVS_WG + threadIdx.x, lane = threadIdx.x & 63u;
-    ReplayWork work = replay_fetch(replay_map, word, map_words);
+    const uint32_t lane = threadIdx.x & 63u;
+    ReplayWork work = replay_fetch(replay_map, map_words);
     const uint32_t n = g.n_ac;
     while (work.pending != 0) {  // wave-uniform
         const uint32_t src = (uint32_t)__builtin_ctzll(work.pending);
         work.pending &= work.pending - 1;
         const uint64_t todo = replay_broadcast(work.mine, src);
         if (!((todo >> lane) & 1ull)) continue;
-        const uint32_t gblock = replay_block(word - lane + src, lane, bpl);
+        const uint32_t gblock = replay_block(work.first + src, lane, bpl);
         const int64_t off = block_offset(gblock, g);
         typename RowVec<1>::type v[8];
         load_rows<1>(gray + off, g.row_pitch, v);
@@ -954,15 +971,15 @@ __global__ __launch_bounds__(SVS_WG, SVS_EXACT_MIN_WAVES) void embed_bgr_replay_
                                                           const uint64_t n_bits, const uint32_t n_words,
                                                           uint64_t *__restrict__ replay_map,
                                                           const uint32_t map_words) {
-    const uint32_t word = blockIdx.x * (uint32_t)SVS_WG + threadIdx.x, lane = threadIdx.x & 63u;
-    ReplayWork work = replay_fetch(replay_map, word, map_words);
+    const uint32_t lane = threadIdx.x & 63u;
+    ReplayWork work = replay_fetch(replay_map, map_words);
     const uint32_t n = g.n_ac;
     while (work.pending != 0) {  // wave-uniform; see embed_replay_kernel
         const uint32_t src = (uint32_t)__builtin_ctzll(work.pending);
         work.pending &= work.pending - 1;
         const uint64_t todo = replay_broadcast(work.mine, src);
         if (!((todo >> lane) & 1ull)) continue;
-        const uint32_t gblock = replay_block(word - lane + src, lane, 1u);
+        const uint32_t gblock = replay_block(work.first + src, lane, 1u);
         const uint8_t *src_px = bgr_in + block_offset_bgr(gblock, g, c.in_row_pitch, c.in_frame_pitch);
         uint32_t ax[8], ay[8];
 #pragma unroll
