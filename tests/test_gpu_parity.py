@@ -759,3 +759,44 @@ def test_drop_in_operator_matches_reference_contract(golden):
     g, s, used = cs.proses_frame_qim_dct(gray, "embed", 7.5, pstr)
     assert used == len(pstr)
     assert cs.proses_frame_qim_dct(s, "extract", 7.5)[:used] == orc.frame_extract(s, 7.5, 63)[:used]
+
+
+def test_replay_map_is_reused_across_calls_sizes_and_streams():
+    """The replay map is one buffer per stream, kept all-zero between calls by the replay pass and grown on demand.
+    Calls of different sizes, block mappings (one / two blocks per lane) and content (all flagged, nothing flagged) are
+    interleaved on two streams; every result must equal the one-shot result of the CPU build of the kernel header."""
+    lib = native.load()
+    rng = np.random.default_rng(12)
+    streams = []
+    for _ in range(2):
+        st = C.c_void_p()
+        native.check(lib.svs_stream_create(C.byref(st)), "stream")
+        streams.append(st)
+    shapes = [(2, 64, 96), (5, 128, 256), (1, 8, 8), (3, 72, 88), (7, 256, 512), (2, 64, 96), (1, 40, 24)]   # 88/8, 24/8 odd
+    n_ac, delta = 3, 8
+    jobs = []
+    for k, (f, h, w) in enumerate(shapes * 2):
+        kind = k % 3
+        if kind == 0:
+            cover = np.full((f, h, w), 100 + k, np.uint8)                    # every block flagged
+        elif kind == 1:
+            cover = rng.integers(16, 240, (f, h, w), dtype=np.uint8)         # nothing flagged
+        else:
+            cover = rng.integers(16, 240, (f, h, w), dtype=np.uint8)
+            cover[:, : h // 2] = 200                                          # half flagged
+        bits = rng.integers(0, 2, batch.capacity_bits(f, h, w, n_ac)).astype(np.uint8)
+        d_in, d_out, d_bits = _Dev(cover.nbytes), _Dev(cover.nbytes), _Dev(batch.pack_bits(bits).nbytes)
+        d_in.put(cover)
+        d_bits.put(batch.pack_bits(bits))
+        st = streams[k % 2]
+        used = batch.embed_device(d_in.ptr.value, d_out.ptr.value, Planes.contiguous(f, h, w), delta, n_ac, d_bits.ptr.value, 0,
+                                  bits.size, stream=st.value, mode="fast")
+        assert used == bits.size
+        jobs.append((cover, bits, d_in, d_out, d_bits))
+    for st in streams:
+        native.check(lib.svs_stream_synchronize(st), "sync")
+    for cover, bits, d_in, d_out, d_bits in jobs:
+        want, _ = emu_embed(cover, delta, n_ac, bits)
+        assert np.array_equal(d_out.get().reshape(cover.shape), want), cover.shape
+    for st in streams:
+        native.check(lib.svs_stream_destroy(st), "destroy")
