@@ -130,7 +130,10 @@ Tuning embed_tuning(int rows, const svs_planes *p, const void *a, const void *b)
 }
 
 Tuning extract_tuning(int rows, const svs_planes *p, const void *a) {
-    Tuning t{false, rows == 1 ? 32u : kEighth};
+    // tile map of the read-only kernels (A/B sweeps: profiles/r01_ab_variants.txt, profiles/r02_ab_extract_chunk.txt): one
+    // coefficient row - runs of 32 tiles per XCD; two rows (n = 8..15) - the identity map (+6.7 % at 600 x 4K, +4.4 % at
+    // 2 400 x 1080p over the contiguous eighth, equal at 300 x 1080p); more rows - VALU-bound, the map does not matter
+    Tuning t{false, rows == 1 ? 32u : (rows == 2 ? 0u : kEighth)};
     t.two_blocks = rows <= 2 && env_chunk("SVS_EXTRACT_BPL", 1) == 2;
     t.chunk = env_chunk("SVS_EXTRACT_XCD_CHUNK", t.chunk);
     t.two_blocks = t.two_blocks && rows_allow_two_blocks(p, a, nullptr);
