@@ -113,11 +113,9 @@ def pf_dct2(x):
     ti2, h2 = c[2].add(c[6]), c[2].add(c[6])
     h6 = ti2.mulc(W).add(tr2.mulc(W))
     h5 = tr2.mulc(W).add(ti2.mulc(W))
-    a0, b0 = c[3].fma(2.0, h0), c[3].fma(2.0, h0)      # fma(2, c3, h0): the product by 2 is exact, one rounding
-    a0.m -= 1; b0.m -= 1                                # (fma() charged a constant error for the exact 2)
     r = [None] * 8
 
-    def f2(a, b):                                       # fma(+-2, a, b)
+    def f2(a, b):                                       # fma(+-2, a, b): the product by 2 is exact, one rounding
         t = a.fma(2.0, b)
         t.m = max(a.m, b.m) + 1
         return t
