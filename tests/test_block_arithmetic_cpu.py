@@ -156,3 +156,52 @@ def test_round_trip_is_error_free_for_delta_ge_8(n_ac, delta):
     assert used == cap
     assert np.array_equal(emu_extract(stego, delta, n_ac), payload)
     assert np.array_equal(orc.batch_extract_bits(stego, delta, n_ac), payload)
+
+
+def test_forward_transforms_differ_by_less_than_the_tie_bound():
+    """SVS_TIE_SLOPE (csrc/svs_block.hpp; derived by tools/tie_bound.py): |c_fast - c_pocketfft| <= slope * c00 for every
+    coefficient of every block of pixels in [0, 255].  Checked here on random, bright, dark, high-contrast and
+    one-dimensional blocks, and the derivation itself is re-run (its slope must not exceed the constant in the header)."""
+    import importlib.util
+    import os
+    import re
+    from testlib import CSRC, REPO
+    lib = hostemu()
+    text = open(os.path.join(CSRC, "svs_block.hpp")).read()
+    m = re.search(r"#define SVS_TIE_SLOPE \(([0-9.e+-]+) \* ([0-9.]+) \+ ([0-9.]+) \* ([0-9.e+-]+)\)", text)
+    slope = float(m.group(1)) * float(m.group(2)) + float(m.group(3)) * float(m.group(4))
+    spec = importlib.util.spec_from_file_location("tie_bound", os.path.join(REPO, "tools", "tie_bound.py"))
+    tb = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(tb)
+    assert tb.main() <= float(m.group(1)) * 1.0001                       # the header's constant covers the derived slope
+    rng = np.random.default_rng(77)
+    blocks = [rng.integers(0, 256, (8, 8)) for _ in range(3000)]
+    blocks += [rng.integers(200, 256, (8, 8)) for _ in range(500)] + [rng.integers(0, 8, (8, 8)) for _ in range(200)]
+    blocks += [rng.choice([0, 255], (8, 8)) for _ in range(500)]
+    blocks += [np.repeat(rng.integers(0, 256, (8, 1)), 8, 1) for _ in range(200)]
+    blocks += [np.full((8, 8), v) for v in (1, 127, 128, 255)]
+    worst = 0.0
+    for blk in blocks:
+        blk = np.ascontiguousarray(blk, np.uint8)
+        fast = np.zeros((8, 8), np.float32)
+        lib.emu_forward_block(blk.ctypes.data, fast.ctypes.data)
+        pf = np.zeros((8, 8), np.float32)
+        cols = np.zeros((8, 8), np.float32)
+        for x in range(8):                                               # vertical first (axis 0), as the reference does
+            src = np.ascontiguousarray(blk[:, x].astype(np.float32))
+            out = np.zeros(8, np.float32)
+            lib.emu_pf_dct2(src.ctypes.data, out.ctypes.data)
+            cols[:, x] = out
+        for u in range(8):
+            src = np.ascontiguousarray(cols[u])
+            out = np.zeros(8, np.float32)
+            lib.emu_pf_dct2(src.ctypes.data, out.ctypes.data)
+            pf[u] = out
+        c00 = float(blk.sum()) / 8.0
+        if c00 == 0:
+            assert np.array_equal(fast, pf)
+            continue
+        err = np.abs(fast.astype(np.float64) - pf.astype(np.float64)).reshape(-1)[1:].max()
+        assert err <= slope * c00, (err, slope * c00)
+        worst = max(worst, err / c00)
+    assert worst < slope / 10                                            # the proven bound is >= 10x what occurs
