@@ -784,19 +784,21 @@ def test_replay_map_is_reused_across_calls_sizes_and_streams():
         else:
             cover = rng.integers(16, 240, (f, h, w), dtype=np.uint8)
             cover[:, : h // 2] = 200                                          # half flagged
-        bits = rng.integers(0, 2, batch.capacity_bits(f, h, w, n_ac)).astype(np.uint8)
+        off = int(rng.integers(0, 100))                                       # stream starts at a bit offset
+        short = int(rng.integers(0, 3 * n_ac))                                # ... and ends inside the last blocks
+        bits = rng.integers(0, 2, off + batch.capacity_bits(f, h, w, n_ac) - short).astype(np.uint8)
         d_in, d_out, d_bits = _Dev(cover.nbytes), _Dev(cover.nbytes), _Dev(batch.pack_bits(bits).nbytes)
         d_in.put(cover)
         d_bits.put(batch.pack_bits(bits))
         st = streams[k % 2]
-        used = batch.embed_device(d_in.ptr.value, d_out.ptr.value, Planes.contiguous(f, h, w), delta, n_ac, d_bits.ptr.value, 0,
-                                  bits.size, stream=st.value, mode="fast")
-        assert used == bits.size
-        jobs.append((cover, bits, d_in, d_out, d_bits))
+        used = batch.embed_device(d_in.ptr.value, d_out.ptr.value, Planes.contiguous(f, h, w), delta, n_ac, d_bits.ptr.value, off,
+                                  bits.size - off, stream=st.value, mode="fast")
+        assert used == bits.size - off
+        jobs.append((cover, bits, off, d_in, d_out, d_bits))
     for st in streams:
         native.check(lib.svs_stream_synchronize(st), "sync")
-    for cover, bits, d_in, d_out, d_bits in jobs:
-        want, _ = emu_embed(cover, delta, n_ac, bits)
+    for cover, bits, off, d_in, d_out, d_bits in jobs:
+        want, _ = emu_embed(cover, delta, n_ac, bits, bit_offset=off)
         assert np.array_equal(d_out.get().reshape(cover.shape), want), cover.shape
     for st in streams:
         native.check(lib.svs_stream_destroy(st), "destroy")
