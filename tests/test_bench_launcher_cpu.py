@@ -1,0 +1,62 @@
+"""CPU tier: `python bench.py --gpus N` without an external launcher becomes the parent of N ranks - it must compose the
+torch.distributed.run command (rendezvous on 127.0.0.1, one process per GPU, its own arguments passed through) and must
+not have imported torch or touched HIP when it does so (never re-exec / fork a process that initialised the GPU)."""
+import json
+import os
+import subprocess
+import sys
+import textwrap
+
+from testlib import REPO
+
+
+def test_parent_composes_the_rank_launch_without_touching_the_gpu():
+    script = textwrap.dedent(f"""
+        import json, subprocess, sys
+        sys.argv = ["bench.py", "--gpus", "4", "--steps", "7", "--rehearse-gloo"]
+        sys.path.insert(0, {REPO!r})
+        seen = {{}}
+        def fake_call(cmd, env=None):
+            seen["cmd"], seen["legacy_ipc"], seen["torch_loaded"] = cmd, env.get("HSA_ENABLE_IPC_MODE_LEGACY"), "torch" in sys.modules
+            return 0
+        subprocess.call = fake_call
+        import bench
+        try:
+            bench.main()
+        except SystemExit as exc:
+            seen["exit"] = exc.code
+        print(json.dumps(seen))
+    """)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    res = subprocess.run([sys.executable, "-c", script], env=env, capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0, res.stderr
+    seen = json.loads(res.stdout.strip().splitlines()[-1])
+    cmd = seen["cmd"]
+    assert seen["exit"] == 0 and seen["torch_loaded"] is False and seen["legacy_ipc"] == "0"
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=4" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 0
+    tail = cmd[cmd.index(os.path.join(REPO, "bench.py")) + 1:]
+    assert tail == ["--gpus", "4", "--steps", "7", "--rehearse-gloo"]
+
+
+def test_a_rank_does_not_launch_again():
+    """under a launcher (RANK set) main() must go on to the rank path, not spawn ranks of its own"""
+    script = textwrap.dedent(f"""
+        import subprocess, sys
+        sys.argv = ["bench.py", "--gpus", "2"]
+        sys.path.insert(0, {REPO!r})
+        def boom(*a, **k):
+            raise AssertionError("a rank tried to launch ranks")
+        subprocess.call = boom
+        import bench
+        bench.launch_ranks = boom
+        try:
+            bench.main()
+        except AssertionError:
+            raise
+        except BaseException as exc:      # no GPU here: the rank path fails later, which is fine
+            print("rank path:", type(exc).__name__)
+    """)
+    env = dict(os.environ, RANK="1", WORLD_SIZE="2", LOCAL_RANK="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999")
+    res = subprocess.run([sys.executable, "-c", script], env=env, capture_output=True, text=True, timeout=300)
+    assert "a rank tried to launch ranks" not in res.stderr and "rank path:" in res.stdout, res.stdout + res.stderr
