@@ -60,7 +60,7 @@ extern "C" {
  *                        - extract: a block with a quantiser input within a proven error bound of a rounding tie is
  *                          recomputed inside the kernel with the pocketfft-identical transform.
  *                      Result: extracted bits identical to the reference's for ANY input frame; stego PSNR within
- *                      0.01 dB of the reference's on any content (measured <= 0.003 dB, tests/test_gpu_parity.py).
+ *                      0.01 dB of the reference's on any content (measured <= 0.006 dB, tests/test_gpu_parity.py).
  *                      Stego pixels can still differ from the reference's where float32 noise decides a single
  *                      pixel's floor or a quantiser near-tie (about 1e-5 of the pixels at n = 3, 1e-3 at n = 10).
  *   SVS_EXACT_POCKETFFT  every float32 operation of scipy.fftpack.dct/idct(norm='ortho') (pocketfft) is
