@@ -311,7 +311,8 @@ def main():
                                    f"full-capacity payload ({cap} bits per GPU), gray planes resident in HBM",
                        "frames_per_gpu": F, "height": H, "width": W, "n_ac": n_ac, "delta": delta,
                        "sharding": "frames" if world > 1 else "none",
-                       "collective": "rccl gather of packed bits" if world > 1 else "none"},
+                       "collective": ("gloo gather of packed bits through host memory (rehearsal)" if args.rehearse_gloo else
+                                      "rccl gather of packed bits") if use_dist else "none"},
             "payload_bit_errors": bit_errors, "payload_ber": bit_errors / (cap * world),
             "psnr_frame0_db": psnr0,
             "kernel_ms": {"embed": embed_ms, "extract": extract_ms},
