@@ -11,7 +11,7 @@ from svsdct import batch
 from testlib import emu_embed, emu_extract
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
-deltas = [1, 2, 3, 4, 5, 6.5, 8, 10, 16, 20, 25, 32, 0.5, 100]
+deltas = [1, 2, 3, 4, 5, 6.5, 8, 10, 16, 20, 25, 32, 0.5, 100, 0, -2]
 for it in range(iters):
     f = int(rng.integers(1, 5)); h = 8 * int(rng.integers(1, 40)); w = 8 * int(rng.integers(1, 60))
     n_ac = int(rng.integers(0, 66)); delta = deltas[int(rng.integers(0, len(deltas)))]
@@ -27,6 +27,9 @@ for it in range(iters):
     assert used == want_used and np.array_equal(stego, want), ("fast embed", it, f, h, w, n_ac, delta)
     packed, n = batch.extract_frames(stego, delta, n_ac, mode="fast")
     assert np.array_equal(np.unpackbits(packed, count=n), emu_extract(stego, delta, n_ac)), ("fast extract", it)
+    for src in (frames, stego):        # FAST extraction is the reference's on any frame (no tie masks)
+        packed, n = batch.extract_frames(src, delta, n_ac, mode="fast")
+        assert np.array_equal(np.unpackbits(packed, count=n), orc.batch_extract_bits(src, delta, n_ac)), ("fast vs oracle", it)
     stego_x, used_x = batch.embed_frames(frames, delta, n_ac, bits, bit_offset=off, n_bits=n_bits, mode="exact")
     if delta > 0 and min(n_ac, 63) > 0 or n_bits == 0:
         ref, ref_used = orc.batch_embed(frames, delta, bits[off:], n_ac)
