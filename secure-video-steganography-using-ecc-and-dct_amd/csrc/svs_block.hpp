@@ -759,12 +759,37 @@ SVS_HD void forward_exact_paired(const uint32_t (&rx)[8], const uint32_t (&ry)[8
 // EXACT embed of one block: full DCT -> QIM on 1..n (first nb take payload) -> full IDCT (vertical
 // first, :168) -> clip + truncate (:171).  A block that is entered is always round-tripped, even when
 // nothing is changed (delta <= 0, n = 0): that is what produces the reference's x -> x-1 artefacts.
+// The 64 coefficients of a CONSTANT block (all pixels = v), pocketfft arithmetic, without transforming 16 lines: every
+// column is the same vector (v, .., v), so one dct2_8 gives the whole vertical pass; its AC outputs are exact zeros
+// (differences of equal values, products and sums of zeros), so rows 1..7 stay zero through the horizontal pass, and row 0 is
+// again a constant vector.  Two transforms instead of sixteen, same bits (the sign of a zero coefficient cannot reach a
+// pixel: x + (-0) = x, and an exactly-zero pixel truncates to 0 either way).
+SVS_HD void forward_exact_paired_constant(float v, pf::f32x2 (&D2)[4][8]) {
+    using pf::f32x2;
+    float col[8], V[8], row[8], D0[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) col[r] = v;
+    pf::dct2_8(col, V);       // V[0] = the column's DC term, V[1..7] = 0
+#pragma unroll
+    for (int x = 0; x < 8; ++x) row[x] = V[0];
+    pf::dct2_8(row, D0);      // D0[0] = DC, D0[1..7] = 0
+    const f32x2 zero = {0.0f, 0.0f};
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int c = 0; c < 8; ++c) D2[q][c] = zero;
+    D2[0][0][0] = D0[0];
+}
+
+// `constant_block`: the caller knows (wave-uniformly) that all 64 pixels are equal - the forward pass is then the two-line
+// shortcut above (used by the replay pass of FAST embedding, where whole letterbox bars arrive)
 template <int U, int QM>
 SVS_HD void embed_block_exact(uint32_t (&rx)[8], uint32_t (&ry)[8], uint32_t n, uint32_t nb, uint32_t hi, uint32_t lo,
-                              const QimParams &qp) {
+                              const QimParams &qp, bool constant_block = false) {
     using pf::f32x2;
     f32x2 D2[4][8];
-    forward_exact_paired(rx, ry, D2);
+    if (constant_block) forward_exact_paired_constant(ubyte_to_float<0>(rx[0]), D2);
+    else forward_exact_paired(rx, ry, D2);
 #pragma unroll
     for (int k = 1; k < 8 * U; ++k) {
         if ((uint32_t)k <= n) {  // wave-uniform

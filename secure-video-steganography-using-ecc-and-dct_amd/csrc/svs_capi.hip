@@ -182,11 +182,11 @@ int launch_embed(int rows, uint64_t total, hipStream_t st, const uint8_t *gray, 
 // second pass of a FAST embed: redo the blocks marked in the replay map with the exact arithmetic (svs_device.hpp)
 int launch_embed_replay(int qm, hipStream_t st, const uint8_t *gray, uint8_t *stego, const svs::Geometry &g,
                         const svs::QimParams &qp, const uint32_t *bits, uint64_t bit_offset, uint64_t n_bits,
-                        uint32_t n_words, uint64_t *replay_map, uint64_t map_words, int bpl) {
+                        uint32_t n_words, uint64_t *replay_map, uint64_t map_words) {
     const dim3 grid(svs::replay_grid(map_words));
 #define SVS_GO(QM)                                                                                                     \
     hipLaunchKernelGGL((svs::embed_replay_kernel<QM>), grid, dim3(SVS_WG), 0, st, gray, stego, g, qp, bits, bit_offset, \
-                       n_bits, n_words, replay_map, (uint32_t)map_words, (uint32_t)bpl)
+                       n_bits, n_words, replay_map, (uint32_t)map_words)
     if (qm == svs::QM_DOUBLE) SVS_GO(svs::QM_DOUBLE);
     else if (qm == svs::QM_POW2) SVS_GO(svs::QM_POW2);
     else SVS_GO(svs::QM_F32);
@@ -568,7 +568,7 @@ int svs_embed_dev(const uint8_t *d_gray, uint8_t *d_stego, const svs_planes *pla
     else SVS_GO(svs::QM_F32);
 #undef SVS_GO
     if (!rc)
-        rc = launch_embed_replay(qm, st, d_gray, d_stego, g, qp, bw, bit_offset, use, (uint32_t)words, d_map, map_words, bpl);
+        rc = launch_embed_replay(qm, st, d_gray, d_stego, g, qp, bw, bit_offset, use, (uint32_t)words, d_map, map_words);
     if (rc) {
         replay_map_discard(st);
         return rc;

@@ -120,6 +120,17 @@ __device__ __forceinline__ void store_rows(uint8_t *dst, int64_t row_pitch, cons
 // BPL = 2 needs an even number of blocks per row and 16-byte aligned rows (host checks).
 // HBM traffic per block: 64 B read + 64 B written + n payload bits read.
 // ---------------------------------------------------------------------------------------
+// bit i of x -> bit 2i (the even bits of a 64-bit word)
+__device__ __forceinline__ uint64_t spread_bits(uint32_t x32) {
+    uint64_t x = x32;
+    x = (x | (x << 16)) & 0x0000FFFF0000FFFFull;
+    x = (x | (x << 8)) & 0x00FF00FF00FF00FFull;
+    x = (x | (x << 4)) & 0x0F0F0F0F0F0F0F0Full;
+    x = (x | (x << 2)) & 0x3333333333333333ull;
+    x = (x | (x << 1)) & 0x5555555555555555ull;
+    return x;
+}
+
 #ifndef SVS_U2_MIN_WAVES
 #define SVS_U2_MIN_WAVES 6  // register target of the two-row embed kernel (80 VGPRs: +0.4..2.8 % over the default 87)
 #endif
@@ -128,9 +139,9 @@ __device__ __forceinline__ void store_rows(uint8_t *dst, int64_t row_pitch, cons
 //
 // REPLAY MAP.  A block whose change is structurally zero (svs::embed_block returns true) must come out of the
 // pocketfft-identical arithmetic instead - 2 000 VALU operations and 140 VGPRs that this kernel cannot afford inline.
-// Such a block is left as it was (not stored) and its lane sets one bit in the replay map: 64-bit word
-// (tile * waves_per_workgroup + wave) * BPL + which-block-of-the-lane, bit = lane.  A wave owns its words and stores its
-// ballot only when it is non-zero.  embed_replay_kernel then redoes exactly those blocks and clears the words it consumed,
+// Such a block is left as it was (not stored) and flagged in the replay map, one bit per block: bit b of 64-bit word w
+// stands for global block 64 w + b.  A wave owns the word(s) of its 64 (128 with two blocks per lane) consecutive blocks
+// and stores them - from its ballot(s) - only when they are non-zero.  embed_replay_kernel then redoes exactly those blocks and clears the words it consumed,
 // so the map - a per-stream buffer owned by the library, zeroed when it is allocated - is all zeros again between calls.
 // On noise-like content nothing is ever flagged: this kernel does not touch the map and the second launch is one read of it.
 template <int U, int QM, int BPL, int NFIX = 0>
@@ -199,15 +210,17 @@ __global__ __launch_bounds__(SVS_WG, (U == 2 ? SVS_U2_MIN_WAVES : 1)) void embed
     const uint64_t mb = BPL == 2 ? __ballot(replay_b) : 0ull;
     if ((ma | mb) != 0 && (threadIdx.x & 63u) == 0) {
         uint64_t *slot = replay_map + ((uint64_t)tile * (SVS_WG / 64) + (threadIdx.x >> 6)) * BPL;
-        slot[0] = ma;
-        if constexpr (BPL == 2) slot[1] = mb;
+        if constexpr (BPL == 2) {  // lane l owns blocks 2l and 2l+1 of the wave's 128: interleave the two ballots
+            slot[0] = spread_bits((uint32_t)ma) | (spread_bits((uint32_t)mb) << 1);
+            slot[1] = spread_bits((uint32_t)(ma >> 32)) | (spread_bits((uint32_t)(mb >> 32)) << 1);
+        } else {
+            slot[0] = ma;
+        }
     }
 }
 
-// global block a bit of the replay map stands for (the inverse of the indexing in embed_kernel)
-__device__ __forceinline__ uint32_t replay_block(uint32_t word, uint32_t bit, uint32_t bpl) {
-    return bpl == 1 ? 64u * word + bit : (word >> 1) * 128u + 2u * bit + (word & 1u);
-}
+// global block a bit of the replay map stands for: bit b of word w = block 64 w + b, whatever BPL the first pass ran with
+__device__ __forceinline__ uint32_t replay_block(uint32_t word, uint32_t bit) { return 64u * word + bit; }
 
 // Tail of the extract kernels: a wavefront's 64*BPL consecutive blocks produce exactly n*BPL aligned
 // 64-bit words of the packed stream.  The wave assembles them in a private LDS array of big-endian dwords
@@ -528,7 +541,7 @@ __global__ __launch_bounds__(SVS_WG, SVS_EXACT_MIN_WAVES) void embed_replay_kern
                                                           const uint32_t *__restrict__ bits, const uint64_t bit_offset,
                                                           const uint64_t n_bits, const uint32_t n_words,
                                                           uint64_t *__restrict__ replay_map,
-                                                          const uint32_t map_words, const uint32_t bpl) {
+                                                          const uint32_t map_words) {
     const uint32_t lane = threadIdx.x & 63u;
     ReplayWork work = replay_fetch(replay_map, map_words);
     const uint32_t n = g.n_ac;
@@ -537,7 +550,7 @@ __global__ __launch_bounds__(SVS_WG, SVS_EXACT_MIN_WAVES) void embed_replay_kern
         work.pending &= work.pending - 1;
         const uint64_t todo = replay_broadcast(work.mine, src);
         if (!((todo >> lane) & 1ull)) continue;
-        const uint32_t gblock = replay_block(work.first + src, lane, bpl);
+        const uint32_t gblock = replay_block(work.first + src, lane);
         const int64_t off = block_offset(gblock, g);
         typename RowVec<1>::type v[8];
         load_rows<1>(gray + off, g.row_pitch, v);
@@ -547,7 +560,13 @@ __global__ __launch_bounds__(SVS_WG, SVS_EXACT_MIN_WAVES) void embed_replay_kern
         const uint64_t first = (uint64_t)gblock * n;
         uint32_t hi, lo;
         payload_window(bits, n_words, bit_offset + first, hi, lo);
-        embed_block_exact<8, QM>(ax, ay, n, block_budget(first, n_bits, n), hi, lo, qp);
+        // letterbox bars and the like: when every block of this pass is constant, the forward transform is two lines
+        uint32_t differs = 0;
+        const uint32_t splat = (ax[0] & 0xffu) * 0x01010101u;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) differs |= (ax[r] ^ splat) | (ay[r] ^ splat);
+        const bool all_constant = __ballot(differs != 0) == 0;   // over the lanes active in this pass
+        embed_block_exact<8, QM>(ax, ay, n, block_budget(first, n_bits, n), hi, lo, qp, all_constant);
 #pragma unroll
         for (int r = 0; r < 8; ++r) { v[r].x = ax[r]; v[r].y = ay[r]; }
         store_rows<1>(stego + off, g.row_pitch, v);
@@ -979,7 +998,7 @@ __global__ __launch_bounds__(SVS_WG, SVS_EXACT_MIN_WAVES) void embed_bgr_replay_
         work.pending &= work.pending - 1;
         const uint64_t todo = replay_broadcast(work.mine, src);
         if (!((todo >> lane) & 1ull)) continue;
-        const uint32_t gblock = replay_block(work.first + src, lane, 1u);
+        const uint32_t gblock = replay_block(work.first + src, lane);
         const uint8_t *src_px = bgr_in + block_offset_bgr(gblock, g, c.in_row_pitch, c.in_frame_pitch);
         uint32_t ax[8], ay[8];
 #pragma unroll

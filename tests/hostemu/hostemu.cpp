@@ -61,10 +61,15 @@ void embed_exact_pair_dispatch(Blk &a, Blk &b, uint32_t n, uint32_t nb_a, uint32
     else svs::embed_block_exact_pair<8, svs::QM_F32>(a.x, a.y, b.x, b.y, n, nb_a, nb_b, hi_a, lo_a, hi_b, lo_b, qp);
 }
 
+bool g_constant_shortcut = false;   // exact == 3: constant blocks take forward_exact_paired_constant, as the replay kernel does
+
 void embed_exact_dispatch(Blk &raw, uint32_t n, uint32_t nb, uint32_t hi, uint32_t lo, const svs::QimParams &qp, int qm) {
-    if (qm == svs::QM_DOUBLE) svs::embed_block_exact<8, svs::QM_DOUBLE>(raw.x, raw.y, n, nb, hi, lo, qp);
-    else if (qm == svs::QM_POW2) svs::embed_block_exact<8, svs::QM_POW2>(raw.x, raw.y, n, nb, hi, lo, qp);
-    else svs::embed_block_exact<8, svs::QM_F32>(raw.x, raw.y, n, nb, hi, lo, qp);
+    bool constant = g_constant_shortcut;
+    for (int r = 0; r < 8 && constant; ++r)
+        constant = raw.x[r] == (raw.x[0] & 0xffu) * 0x01010101u && raw.y[r] == (raw.x[0] & 0xffu) * 0x01010101u;
+    if (qm == svs::QM_DOUBLE) svs::embed_block_exact<8, svs::QM_DOUBLE>(raw.x, raw.y, n, nb, hi, lo, qp, constant);
+    else if (qm == svs::QM_POW2) svs::embed_block_exact<8, svs::QM_POW2>(raw.x, raw.y, n, nb, hi, lo, qp, constant);
+    else svs::embed_block_exact<8, svs::QM_F32>(raw.x, raw.y, n, nb, hi, lo, qp, constant);
 }
 
 // -> true: some quantiser input is within the forward error bound of a tie (svs::extract_block's return value)
@@ -100,6 +105,7 @@ uint64_t emu_embed(const uint8_t *gray, uint8_t *stego, int F, int H, int W, dou
                    const uint8_t *bits, uint64_t bits_bytes, uint64_t bit_offset, uint64_t n_bits, int exact,
                    uint64_t *n_replayed) {
     if (n_replayed) *n_replayed = 0;
+    g_constant_shortcut = exact == 3;
     const int n = n_ac < 0 ? 0 : (n_ac > 63 ? 63 : n_ac);
     const uint64_t bpf = (uint64_t)(H / 8) * (W / 8), total = bpf * F;
     std::memcpy(stego, gray, (size_t)F * H * W);

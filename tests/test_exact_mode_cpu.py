@@ -83,3 +83,21 @@ def test_pair_form_equals_the_one_block_form(golden):
             one, u1 = emu_embed(frames, delta, n_ac, bits, bit_offset=11, exact=1)
             two, u2 = emu_embed(frames, delta, n_ac, bits, bit_offset=11, exact=2)
             assert u1 == u2 and np.array_equal(one, two), (n_ac, delta, n_bits)
+
+
+def test_constant_block_shortcut_equals_the_full_forward_transform():
+    """forward_exact_paired_constant (two pocketfft lines instead of sixteen for a block of 64 equal pixels - what the replay
+    pass of FAST embedding uses on letterbox bars) gives the bytes of the full transform for every pixel value, with payload
+    bits that change nothing, one coefficient or all of them, and for delta <= 0 (round trip only)."""
+    rng = np.random.default_rng(5)
+    frames = np.repeat(np.repeat(np.arange(256, dtype=np.uint8).reshape(16, 16), 8, axis=0), 8, axis=1)[None]   # 256 constant blocks
+    for n_ac, delta in ((3, 8), (3, 16), (7, 4), (10, 20), (63, 4), (5, 0.3), (4, 0), (0, 8)):
+        for fill in (0, 1, None):
+            cap = 256 * max(0, min(n_ac, 63))
+            bits = (rng.integers(0, 2, max(cap, 1)) if fill is None else np.full(max(cap, 1), fill)).astype(np.uint8)
+            full, u1 = emu_embed(frames, delta, n_ac, bits, exact=1)
+            fast, u2 = emu_embed(frames, delta, n_ac, bits, exact=3)
+            assert u1 == u2 and np.array_equal(full, fast), (n_ac, delta, fill)
+            ref, _ = orc.batch_embed(frames, delta, bits, n_ac) if (delta > 0 and n_ac > 0) else (None, None)
+            if ref is not None:
+                assert np.array_equal(fast, ref), (n_ac, delta, fill)
