@@ -185,7 +185,7 @@ int launch_embed_replay(int qm, hipStream_t st, const uint8_t *gray, uint8_t *st
                         uint32_t n_words, uint64_t *replay_map, uint64_t map_words) {
     const dim3 grid(svs::replay_grid(map_words));
 #define SVS_GO(QM)                                                                                                     \
-    hipLaunchKernelGGL((svs::embed_replay_kernel<QM>), grid, dim3(SVS_WG), 0, st, gray, stego, g, qp, bits, bit_offset, \
+    hipLaunchKernelGGL((svs::embed_replay_kernel<QM>), grid, dim3(SVS_REPLAY_WG), 0, st, gray, stego, g, qp, bits, bit_offset, \
                        n_bits, n_words, replay_map, (uint32_t)map_words)
     if (qm == svs::QM_DOUBLE) SVS_GO(svs::QM_DOUBLE);
     else if (qm == svs::QM_POW2) SVS_GO(svs::QM_POW2);
@@ -825,7 +825,7 @@ int svs_embed_bgr_dev(const uint8_t *d_bgr_in, int64_t in_row_pitch, int64_t in_
                                              kernel_bits, words, d_map);                                                  \
     if (!rc && replay) {                                                                                                 \
         hipLaunchKernelGGL((svs::embed_bgr_replay_kernel<QM>), dim3(svs::replay_grid(map_words)),                        \
-                           dim3(SVS_WG), 0, st, d_bgr_in, d_bgr_out, g, c, qp, bw, bit_offset, kernel_bits, words, d_map,  \
+                           dim3(SVS_REPLAY_WG), 0, st, d_bgr_in, d_bgr_out, g, c, qp, bw, bit_offset, kernel_bits, words, d_map,  \
                            (uint32_t)map_words);                                                                         \
         if (hipGetLastError() != hipSuccess) rc = fail(SVS_ERR_HIP, "embed_bgr_replay_kernel launch failed");            \
     }

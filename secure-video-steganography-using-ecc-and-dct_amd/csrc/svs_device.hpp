@@ -507,6 +507,9 @@ __global__ __launch_bounds__(SVS_WG, SVS_EXACT2_MIN_WAVES) void embed_exact_pair
 #ifndef SVS_REPLAY_WORDS
 #define SVS_REPLAY_WORDS 32
 #endif
+#ifndef SVS_REPLAY_WG
+#define SVS_REPLAY_WG 256  // threads per workgroup of the replay kernels: with an empty map the pass costs its workgroup count
+#endif
 struct ReplayWork {
     uint64_t mine;     // this lane's map word
     uint64_t pending;  // ballot: lanes of the wave whose word is non-zero
@@ -514,7 +517,7 @@ struct ReplayWork {
 };
 __device__ __forceinline__ ReplayWork replay_fetch(uint64_t *__restrict__ replay_map, uint32_t map_words) {
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wave = blockIdx.x * (uint32_t)(SVS_WG / 64) + (threadIdx.x >> 6);
+    const uint32_t wave = blockIdx.x * (uint32_t)(SVS_REPLAY_WG / 64) + (threadIdx.x >> 6);
     ReplayWork w;
     w.first = wave * (uint32_t)SVS_REPLAY_WORDS;
     const uint32_t word = w.first + lane;
@@ -526,7 +529,7 @@ __device__ __forceinline__ ReplayWork replay_fetch(uint64_t *__restrict__ replay
 }
 // workgroups a replay launch needs for `map_words` words
 __host__ __device__ inline uint32_t replay_grid(uint64_t map_words) {
-    const uint64_t per_wg = (uint64_t)(SVS_WG / 64) * SVS_REPLAY_WORDS;
+    const uint64_t per_wg = (uint64_t)(SVS_REPLAY_WG / 64) * SVS_REPLAY_WORDS;
     return (uint32_t)((map_words + per_wg - 1) / per_wg);
 }
 __device__ __forceinline__ uint64_t replay_broadcast(uint64_t v, uint32_t src_lane) {  // src_lane: wave-uniform
@@ -536,7 +539,7 @@ __device__ __forceinline__ uint64_t replay_broadcast(uint64_t v, uint32_t src_la
 }
 
 template <int QM>
-__global__ __launch_bounds__(SVS_WG, SVS_EXACT_MIN_WAVES) void embed_replay_kernel(const uint8_t *gray, uint8_t *stego,
+__global__ __launch_bounds__(SVS_REPLAY_WG, SVS_EXACT_MIN_WAVES) void embed_replay_kernel(const uint8_t *gray, uint8_t *stego,
                                                           const Geometry g, const QimParams qp,
                                                           const uint32_t *__restrict__ bits, const uint64_t bit_offset,
                                                           const uint64_t n_bits, const uint32_t n_words,
@@ -984,7 +987,7 @@ __global__ __launch_bounds__(SVS_WG) void embed_bgr_kernel(const uint8_t *bgr_in
 // with the exact arithmetic (gray reference frame: already written by the first pass); work distribution as in
 // embed_replay_kernel.
 template <int QM>
-__global__ __launch_bounds__(SVS_WG, SVS_EXACT_MIN_WAVES) void embed_bgr_replay_kernel(const uint8_t *bgr_in, uint8_t *bgr_out,
+__global__ __launch_bounds__(SVS_REPLAY_WG, SVS_EXACT_MIN_WAVES) void embed_bgr_replay_kernel(const uint8_t *bgr_in, uint8_t *bgr_out,
                                                           const Geometry g, const ColourParams c, const QimParams qp,
                                                           const uint32_t *__restrict__ bits, const uint64_t bit_offset,
                                                           const uint64_t n_bits, const uint32_t n_words,
