@@ -68,6 +68,15 @@ extern "C" {
  *                      reference's round-trip artefacts are bit-identical to the reference.  About 2.5x the
  *                      arithmetic: VALU-bound. */
 #define SVS_EXACT_POCKETFFT 1u
+/*   SVS_EXACT_GUARDED  the same bit-identical result as SVS_EXACT_POCKETFFT, obtained at (nearly) FAST speed: the embed
+ *                      kernel computes the payload coefficients exactly as pocketfft does, predicts every stego pixel
+ *                      from the sparse inverse of the coefficient changes, and keeps that prediction only where a
+ *                      rigorous per-block bound on the reference's float32 round-trip noise (tools/guard_bound.py)
+ *                      proves the truncation cannot differ; the few per cent of blocks it cannot decide are redone
+ *                      inside the same kernel with the pocketfft-identical arithmetic.  Applies to n_ac <= 7 and
+ *                      0.25 <= delta <= 4096; other calls (and extraction) run the SVS_EXACT_POCKETFFT kernels, so the
+ *                      flag is always safe to pass. */
+#define SVS_EXACT_GUARDED 2u
 
 /* Geometry of a batch of gray planes. */
 typedef struct svs_planes {

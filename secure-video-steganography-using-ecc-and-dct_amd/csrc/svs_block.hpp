@@ -311,7 +311,8 @@ struct QimParams {
     float inv_delta_f;  // 1 / delta_f   - exact when delta is a power of two (QM_POW2)
     double delta_d;     // delta         - multiplier when (double)delta_f != delta (QM_DOUBLE)
     float tie_slope;    // FAST extraction: c00 * tie_slope bounds |c_fast/delta - c_pocketfft/delta| (see TIE_SLOPE)
-    float pad;
+    // GUARDED embed (embed_block_guarded): BETA = g_sum * (sum of pixels) + g_resid * sqrt(64 sum p^2 - (sum p)^2) + g_delta
+    float g_sum, g_resid, g_delta;
 };
 
 // FAST extraction and rounding ties.  The FMA-factored forward transform (forward_rows) and pocketfft's are two float32
@@ -836,6 +837,122 @@ SVS_HD void embed_block_exact(uint32_t (&rx)[8], uint32_t (&ry)[8], uint32_t n, 
     }
 }
 
+// =====================================================================================================
+// GUARDED mode: the reference's stego pixels, bit for bit, at the cost of the FAST path for almost every block.
+//
+// The reference's output for a block is trunc(clip(out)), out = pf_dct3(pf_dct3(D')) in float32 (config_and_setup.py:
+// 166-171).  embed_block_guarded computes, with a handful of operations,
+//   * the payload-carrying coefficients EXACTLY as pocketfft does (so every quantiser decision q_k is the reference's),
+//   * pred = X + G(change): the pixel plus the sparse inverse of the n coefficient changes, and
+//   * BETA, a rigorous bound on |out - pred| for this block (tools/guard_bound.py: first-order running error analysis of
+//     every operation of svs::pf::dct2_8 / dct3_8, stage-wise Cauchy-Schwarz over the block's energy):
+//         BETA = u' * (KDC * mean + KE * ||X - mean||_2 + KD * (1.5 delta + 0.01)) + 2^-20,   u' = 2^-24 (1 + 2^-10).
+// If every pred is farther than BETA from the integers, floor(pred) IS floor(out) for all 64 pixels and the cheap result
+// is the reference's (values outside [0, 255] clip to the same byte either way; flagging them too is merely conservative).
+// Otherwise the function returns true and the caller redoes the block with the pocketfft-identical arithmetic
+// (embed_block_exact on the host emulation; the 8-lanes-per-block replay inside the kernel, svs_device.hpp).
+// With one coefficient row (n <= 7) the change is the same in all 8 rows of a column, so only 8 values are tested and a
+// noise block (mean 128, sigma 65, delta 8) is flagged with probability 16 * BETA = 2.4 %; smooth content 0.6 %.
+// Constants printed by tools/guard_bound.py (tests/test_guard_bound_cpu.py re-derives them):
+#define SVS_GUARD_KDC 17.0001      // per unit of the mean pixel value
+#define SVS_GUARD_KE 39.40         // per unit of ||X - mean||_2
+#define SVS_GUARD_KD_U1 197.07     // per unit of 1.5 delta + 0.01, at most 7 modified coefficients
+#define SVS_GUARD_KD_U2 491.16     // at most 15 modified coefficients
+#define SVS_GUARD_UEFF (5.9604644775390625e-8 * (1.0 + 0.0009765625))
+// delta range the guarded path is used for (outside it the caller takes the exact kernel): below, the changes are smaller
+// than BETA and every block would be flagged; above, BETA itself exceeds 1/8
+#define SVS_GUARD_DELTA_MIN 0.25
+#define SVS_GUARD_DELTA_MAX 4096.0
+
+SVS_HD uint32_t dot4_u8(uint32_t a, uint32_t b, uint32_t acc) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_udot4(a, b, acc, false);   // v_dot4_u32_u8
+#else
+    for (int i = 0; i < 4; ++i) acc += ((a >> (8 * i)) & 0xffu) * ((b >> (8 * i)) & 0xffu);
+    return acc;
+#endif
+}
+
+SVS_HD float guard_sqrt(float v) {   // any sqrt accurate to a few ulp will do: BETA's constants carry 2^-18 of slack
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_sqrtf(v);
+#else
+    return sqrtf(v);
+#endif
+}
+
+// one coefficient row (n <= 7).  On return rx/ry hold the block's stego pixels iff the result is false.
+template <int QM>
+SVS_HD bool embed_block_guarded(uint32_t (&rx)[8], uint32_t (&ry)[8], uint32_t n, uint32_t nb, uint32_t hi, uint32_t lo,
+                                const QimParams &qp) {
+    // vertical pass, row 0 only: pocketfft's X[0] of a column of integers is fl(colsum * sqrt(2)/4) - its sums are exact
+    // integers and the one product rounds once - which is what the packed 16-bit column sums give (SVS_A0 is that float)
+    float V[8];
+    uint32_t S = 0, Q = 0;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        uint32_t te = 0, to = 0;   // columns (0, 2) and (1, 3) of this half as 16-bit lanes, each <= 2040
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const uint32_t w = half ? ry[r] : rx[r];
+            te += w & 0x00ff00ffu;
+            to += (w >> 8) & 0x00ff00ffu;
+            Q = dot4_u8(w, w, Q);
+        }
+        V[4 * half + 0] = (float)(te & 0xffffu) * SVS_A0;
+        V[4 * half + 1] = (float)(to & 0xffffu) * SVS_A0;
+        V[4 * half + 2] = (float)(te >> 16) * SVS_A0;
+        V[4 * half + 3] = (float)(to >> 16) * SVS_A0;
+        const uint32_t t = te + to;
+        S += (t & 0xffffu) + (t >> 16);
+    }
+    float D[8];
+    pf::dct2_8(V, D);   // row 0 of the coefficient matrix, bit-identical to scipy's
+#pragma unroll
+    for (int k = 1; k < 8; ++k) {
+        float change = 0.0f;
+        if ((uint32_t)k <= n) {  // wave-uniform
+            const int i = k - 1;
+            const int bit = (int)window_bit(hi, lo, i);
+            const float c = D[k];
+            int q = quant_index<QM>(c, qp);
+            q += bit - (q & 1);
+            float cn;
+            if constexpr (QM == QM_DOUBLE) cn = (float)((double)q * qp.delta_d);
+            else cn = (float)q * qp.delta_f;
+            change = ((uint32_t)i < nb) ? cn - c : 0.0f;
+        }
+        D[k] = change;
+    }
+    D[0] = 0.0f;
+    float P[8];
+    idct8<8, true>(D, P);
+    // BETA for this block: 64 Q - S^2 = 64 * (sum of squared deviations from the mean), an exact integer < 2^32
+    const float spread = guard_sqrt((float)(64u * Q - S * S));
+    const float beta = fmaf(qp.g_sum, (float)S, fmaf(qp.g_resid, spread, qp.g_delta));
+    float worst = 0.0f;   // largest |frac(change) - 1/2| over the 8 columns
+#define SVS_OUTCOL(X, W, B)                                                           \
+    {                                                                                 \
+        const float ch = P[X] * SVS_A0, fl = floorf(ch);                              \
+        worst = fmaxf(worst, fabsf((ch - fl) - 0.5f));                                \
+        _Pragma("unroll") for (int y = 0; y < 8; ++y)                                 \
+            W[y] = put_pixel<B>(ubyte_to_float<B>(W[y]) + fl, W[y]);                  \
+    }
+    SVS_OUTCOL(0, rx, 0) SVS_OUTCOL(1, rx, 1) SVS_OUTCOL(2, rx, 2) SVS_OUTCOL(3, rx, 3)
+    SVS_OUTCOL(4, ry, 0) SVS_OUTCOL(5, ry, 1) SVS_OUTCOL(6, ry, 2) SVS_OUTCOL(7, ry, 3)
+#undef SVS_OUTCOL
+    return nb > 0 && !(worst < 0.5f - beta);   // nb == 0: the reference never enters the block (:130,:132)
+}
+
+// BETA's coefficients for `rows` coefficient rows (1 or 2), rounded up; host side
+inline void make_guard(double delta, int rows, QimParams *qp) {
+    const double up = 1.0 + 0x1p-18;   // float evaluation of BETA in the kernel: conversions, sqrt, two FMAs
+    const double kd = rows <= 1 ? SVS_GUARD_KD_U1 : SVS_GUARD_KD_U2;
+    qp->g_sum = (float)(SVS_GUARD_UEFF * SVS_GUARD_KDC / 64.0 * up);
+    qp->g_resid = (float)(SVS_GUARD_UEFF * SVS_GUARD_KE / 8.0 * up);
+    qp->g_delta = (float)((SVS_GUARD_UEFF * kd * (1.5 * delta + 0.01) + 0x1p-20 + 0x1p-22) * up);
+}
+
 // EXACT embed of TWO horizontally adjacent blocks at once: every value is a pair (block A, block B) and every transform
 // instruction a packed-FP32 one (v_pk_add / v_pk_mul / v_pk_fma_f32, each component rounding exactly like the scalar
 // operation).  Unlike embed_block_exact - which pairs two LINES of one block and has to transpose 2x2 sub-blocks between
@@ -935,7 +1052,7 @@ inline int make_qim(double delta, QimParams *qp) {
     qp->inv_delta_f = 1.0f / qp->delta_f;
     qp->delta_d = delta;
     qp->tie_slope = (float)(SVS_TIE_SLOPE / (double)qp->delta_f) * 1.0000002f;  // rounded up
-    qp->pad = 0.0f;
+    qp->g_sum = qp->g_resid = qp->g_delta = 0.0f;   // make_guard
     if ((double)qp->delta_f != delta) return QM_DOUBLE;
     int e = 0;
     const bool pow2 = frexp(delta, &e) == 0.5 && e > -100 && e < 100;

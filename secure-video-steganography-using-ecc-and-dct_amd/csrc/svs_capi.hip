@@ -325,6 +325,27 @@ int launch_embed_exact(int qm, uint64_t total, hipStream_t st, const uint8_t *gr
     return SVS_OK;
 }
 
+// GUARDED embed (svs_device.hpp): one launch, bit-identical to launch_embed_exact
+unsigned long long *g_guard_counter = nullptr;   // measurement hook (svs_guard_counter_set): blocks redone exactly
+
+int launch_embed_guarded(int qm, uint64_t total, hipStream_t st, const uint8_t *gray, uint8_t *stego, const svs::Geometry &g,
+                         const svs::QimParams &qp, const uint32_t *bits, uint64_t bit_offset, uint64_t n_bits,
+                         uint32_t n_words) {
+    const dim3 grid((uint32_t)((total + SVS_WG - 1) / SVS_WG));
+    // the kernel's own LDS (worklist + transposition tiles, 29.7 KB) already limits a CU to five workgroups - the occupancy
+    // the streaming embed kernels are fastest at (profiles/r01_ab_occupancy.txt); SVS_EMBED_WG_PER_CU lowers it further
+    const uint32_t lds_pad = lds_pad_for(env_chunk("SVS_EMBED_WG_PER_CU", 0), 29712);
+#define SVS_GO(QM)                                                                                                       \
+    hipLaunchKernelGGL((svs::embed_guarded_kernel<QM>), grid, dim3(SVS_WG), lds_pad, st, gray, stego, g, qp, bits, bit_offset, \
+                       n_bits, n_words, g_guard_counter)
+    if (qm == svs::QM_DOUBLE) SVS_GO(svs::QM_DOUBLE);
+    else if (qm == svs::QM_POW2) SVS_GO(svs::QM_POW2);
+    else SVS_GO(svs::QM_F32);
+#undef SVS_GO
+    SVS_HIP(hipGetLastError());
+    return SVS_OK;
+}
+
 template <int QM>
 int launch_extract_exact(int rows, uint64_t total, hipStream_t st, const uint8_t *gray, const svs::Geometry &g,
                          const svs::QimParams &qp, uint8_t *out, uint64_t out_bytes) {
@@ -507,7 +528,23 @@ int svs_embed_dev(const uint8_t *d_gray, uint8_t *d_stego, const svs_planes *pla
     g.xcd_chunk = tune.chunk;
     svs::QimParams qp;
     const int qm = make_qim(use == 0 ? 1.0 : delta, &qp);
-    if (flags & ~SVS_EXACT_POCKETFFT) return fail(SVS_ERR_INVALID_ARG, "unknown flags 0x%x", flags);
+    if (flags & ~(SVS_EXACT_POCKETFFT | SVS_EXACT_GUARDED)) return fail(SVS_ERR_INVALID_ARG, "unknown flags 0x%x", flags);
+    // SVS_EXACT_GUARDED: the reference's pixels through the guarded kernel where it applies (one coefficient row, something
+    // to embed, delta inside the range its error bound is useful for) - everything else takes the plain exact kernels below
+    if ((flags & SVS_EXACT_GUARDED) && use > 0 && rows_for(n) == 1 && delta >= SVS_GUARD_DELTA_MIN &&
+        delta <= SVS_GUARD_DELTA_MAX && env_chunk("SVS_GUARDED_OFF", 0) == 0) {
+        const uint64_t words_g = ((bit_offset + use + 7) / 8 + 3) / 4;
+        if (words_g >= (1ull << 32)) return fail(SVS_ERR_INVALID_ARG, "payload too large for one call");
+        svs::make_guard(delta, 1, &qp);
+        g.xcd_chunk = env_chunk("SVS_EMBED_XCD_CHUNK", kEighth);
+        if (int rc = launch_embed_guarded(qm, total, st, d_gray, d_stego, g, qp,
+                                          reinterpret_cast<const uint32_t *>(d_bits_packed), bit_offset, use,
+                                          (uint32_t)words_g))
+            return rc;
+        if (n_embedded) *n_embedded = use;
+        return SVS_OK;
+    }
+    if (flags & SVS_EXACT_GUARDED) flags = SVS_EXACT_POCKETFFT;
     // SVS_EXACT_BPL=2 (experiment knob): exact arithmetic on two adjacent blocks per lane with every transform instruction
     // packed over the pair (embed_exact_pair_kernel).  Measured SLOWER than the one-block kernel (3.54 vs 3.16 ms at n = 3,
     // 4.83 vs 3.38 ms at n = 10, profiles/r02_ab_exact_pair.txt): a v_pk_*_f32 costs two issue slots on this chip, so
@@ -604,7 +641,8 @@ int svs_extract_dev(const uint8_t *d_gray, const svs_planes *planes, double delt
         const int qm = make_qim(delta, &qp);     // the double mode only differs in requantisation: not needed here
         const int rows = rows_for(n);
         int rc;
-        if (flags & ~SVS_EXACT_POCKETFFT) return fail(SVS_ERR_INVALID_ARG, "unknown flags 0x%x", flags);
+        if (flags & ~(SVS_EXACT_POCKETFFT | SVS_EXACT_GUARDED)) return fail(SVS_ERR_INVALID_ARG, "unknown flags 0x%x", flags);
+        if (flags & SVS_EXACT_GUARDED) flags = SVS_EXACT_POCKETFFT;   // extraction: the pocketfft-identical kernels
         // With one coefficient row (n <= 7) the pocketfft-identical forward transform costs 0.2-3 % (the kernel stays
         // HBM-bound; in-process A/B in profiles/r01_ab_quant_exact.txt), so FAST mode uses it too and extraction is
         // bit-identical to the reference for ANY input frame.  With more rows it costs ~17 % and stays opt-in.
@@ -779,7 +817,8 @@ int svs_embed_bgr_dev(const uint8_t *d_bgr_in, int64_t in_row_pitch, int64_t in_
     if (int rc = make_geometry(planes, n_ac, &g, &total)) return rc;
     if (n_embedded) *n_embedded = 0;
     if (total == 0) return SVS_OK;
-    if (flags & ~SVS_EXACT_POCKETFFT) return fail(SVS_ERR_INVALID_ARG, "unknown flags 0x%x", flags);
+    if (flags & ~(SVS_EXACT_POCKETFFT | SVS_EXACT_GUARDED)) return fail(SVS_ERR_INVALID_ARG, "unknown flags 0x%x", flags);
+    if (flags & SVS_EXACT_GUARDED) flags = SVS_EXACT_POCKETFFT;   // the fused colour path has no guarded kernel (yet)
     if (d_gray_ref && ((uintptr_t)d_gray_ref % 8)) return fail(SVS_ERR_INVALID_ARG, "gray pointer must be 8-byte aligned");
     svs::ColourParams c;
     if (int rc = colour_params(planes, d_bgr_in, in_row_pitch, in_frame_pitch, d_bgr_out, out_row_pitch, out_frame_pitch,
@@ -1061,6 +1100,13 @@ int svs_bit_errors_dev(const uint8_t *d_a_packed, const uint8_t *d_b_packed, uin
     hipLaunchKernelGGL(svs::bit_errors_kernel, dim3(blocks), dim3(256), 0, st, d_a_packed, d_b_packed, n_bits,
                        reinterpret_cast<unsigned long long *>(d_count));
     SVS_HIP(hipGetLastError());
+    return SVS_OK;
+}
+
+// measurement hook (not part of the product ABI): device counter (uint64, caller-zeroed) that guarded embed launches add
+// the number of blocks they redid with the exact arithmetic to; NULL switches it off
+int svs_guard_counter_set(void *d_counter) {
+    g_guard_counter = reinterpret_cast<unsigned long long *>(d_counter);
     return SVS_OK;
 }
 

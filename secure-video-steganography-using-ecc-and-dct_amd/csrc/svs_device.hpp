@@ -576,6 +576,158 @@ __global__ __launch_bounds__(SVS_REPLAY_WG, SVS_EXACT_MIN_WAVES) void embed_repl
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// GUARDED embed (include/svsdct.h SVS_EXACT_GUARDED, one coefficient row): the reference's pixels bit for bit, at the FAST
+// kernel's traffic and nearly its instruction count.
+//   phase 1  lane = block: svs::embed_block_guarded - pocketfft-identical payload coefficients, sparse inverse of the
+//            change, and the per-block error bound that decides whether floor(pixel + change) is certain to be the
+//            reference's truncation for all 64 pixels (a few % of the blocks are not: svs_block.hpp "GUARDED mode").
+//   phase 2  the workgroup's undecided blocks are compacted into an LDS worklist (one LDS atomic per wave) and redone
+//            with the pocketfft-identical arithmetic by EIGHT LANES PER BLOCK: lane r of a group transforms column r,
+//            then row r, of its block - the four 1-D passes of the reference (vertical / horizontal forward, vertical /
+//            horizontal inverse, config_and_setup.py:135,168) with a transposition through a wave-private LDS tile in
+//            between.  Every value is produced by the same svs::pf operation sequence as in embed_block_exact, so the
+//            bits are the same; what changes is the shape: about 40 VGPRs and 430 instructions per pass of 8 blocks
+//            instead of 140 VGPRs and 2 100 per pass of 64 - affordable inside the streaming kernel, and dense when only
+//            a handful of the workgroup's 256 blocks need it.
+//   phase 3  every lane stores its block (its own result or the one it collects from the worklist): the wave's stores
+//            cover whole 512-byte row segments exactly as in the FAST kernel - no partial lines, no second launch, no
+//            extra HBM traffic.
+// ---------------------------------------------------------------------------------------
+struct GuardEntry {
+    uint32_t px[16];   // rows as (low dword, high dword) pairs: the original pixels in, the exact stego pixels out
+    uint32_t hi, lo;   // payload window of the block
+    uint32_t nb;       // bits the block takes
+    uint32_t pad;
+};
+#define SVS_GUARD_TILE 72   // floats per block of the transposition tile: element (i, j) at 9 i + j; 72 = 8 (mod 64) keeps the
+                            // eight groups of a wave on different LDS banks in both directions
+
+template <int QM>
+__device__ __forceinline__ void guard_replay8(GuardEntry *e, float *t, uint32_t r, uint32_t n, const QimParams &qp) {
+    float a[8], b[8];
+    // vertical forward transform of pixel column r
+    {
+        const uint32_t sh = 8u * (r & 3u), half = r >> 2;
+#pragma unroll
+        for (int y = 0; y < 8; ++y) a[y] = (float)((e->px[2 * y + half] >> sh) & 0xffu);
+    }
+    pf::dct2_8(a, b);                       // b[u] = V[u][r]
+#pragma unroll
+    for (int u = 0; u < 8; ++u) t[9 * u + r] = b[u];
+    wave_lds_fence();
+#pragma unroll
+    for (int x = 0; x < 8; ++x) a[x] = t[9 * r + x];   // V[r][x]
+    wave_lds_fence();
+    pf::dct2_8(a, b);                       // b[v] = D[r][v]: coefficient row r
+    // QIM on flat indices k = 8 r + v in 1..n (config_and_setup.py:139-158)
+    const uint32_t hi = e->hi, lo = e->lo, nb = e->nb;
+#pragma unroll
+    for (int v = 0; v < 8; ++v) {
+        const uint32_t k = 8u * r + v;
+        if (k >= 1u && k <= n) {
+            const int i = (int)k - 1;
+            const int bit = (int)window_bit(hi, lo, i);
+            const float c = b[v];
+            int q = quant_index<QM>(c, qp);
+            q += bit - (q & 1);
+            float cn;
+            if constexpr (QM == QM_DOUBLE) cn = (float)((double)q * qp.delta_d);
+            else cn = (float)q * qp.delta_f;
+            b[v] = ((uint32_t)i < nb) ? cn : c;
+        }
+    }
+    // vertical inverse first (axis 0, :168): lane r takes coefficient column r
+#pragma unroll
+    for (int v = 0; v < 8; ++v) t[9 * r + v] = b[v];
+    wave_lds_fence();
+#pragma unroll
+    for (int u = 0; u < 8; ++u) a[u] = t[9 * u + r];   // D'[u][r]
+    wave_lds_fence();
+    pf::dct3_8(a, b);                       // b[y] = P[y][r]
+#pragma unroll
+    for (int y = 0; y < 8; ++y) t[9 * y + r] = b[y];
+    wave_lds_fence();
+#pragma unroll
+    for (int v = 0; v < 8; ++v) a[v] = t[9 * r + v];   // P[r][v]
+    pf::dct3_8(a, b);                       // pixel row r
+    uint32_t lo4, hi4;
+    store_row_trunc(b[0], b[1], b[2], b[3], b[4], b[5], b[6], b[7], lo4, hi4);   // np.uint8(np.clip(.)) (:171)
+    e->px[2 * r] = lo4;
+    e->px[2 * r + 1] = hi4;
+}
+
+template <int QM>
+__global__ __launch_bounds__(SVS_WG) void embed_guarded_kernel(const uint8_t *gray,   // may alias stego
+                                                             uint8_t *stego, const Geometry g, const QimParams qp,
+                                                             const uint32_t *__restrict__ bits, const uint64_t bit_offset,
+                                                             const uint64_t n_bits, const uint32_t n_words,
+                                                             unsigned long long *__restrict__ replay_counter) {
+    __shared__ GuardEntry entries[SVS_WG];
+    __shared__ float tiles[SVS_WG / 64][8 * SVS_GUARD_TILE];
+    __shared__ uint32_t count;
+    if (threadIdx.x == 0) count = 0;
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t gblock = tile_id(g.xcd_chunk) * (uint32_t)SVS_WG + threadIdx.x;
+    const uint32_t n = g.n_ac;
+    const bool live = gblock < g.total_blocks;
+    bool undecided = false, write = false;
+    typename RowVec<1>::type v[8];
+    int64_t off = 0;
+    uint32_t hi = 0, lo = 0, nb = 0;
+    if (live) {
+        off = block_offset(gblock, g);
+        load_rows<1>(gray + off, g.row_pitch, v);
+        const uint64_t first = (uint64_t)gblock * n;
+        write = stego != gray;           // past the budget: byte-identical copy (:130,:132)
+        if (first < n_bits) {
+            write = true;
+            uint32_t ax[8], ay[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) { ax[r] = v[r].x; ay[r] = v[r].y; }
+            payload_window(bits, n_words, bit_offset + first, hi, lo);
+            nb = block_budget(first, n_bits, n);
+            undecided = embed_block_guarded<QM>(ax, ay, n, nb, hi, lo, qp);
+            if (!undecided) {
+#pragma unroll
+                for (int r = 0; r < 8; ++r) { v[r].x = ax[r]; v[r].y = ay[r]; }
+            }
+        }
+    }
+    // worklist slots: one LDS atomic per wave that has undecided blocks
+    const uint64_t mask = __ballot(undecided);
+    uint32_t slot = 0;
+    if (mask != 0) {
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(&count, (uint32_t)__popcll(mask));
+        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+        slot = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+        if (undecided) {
+            GuardEntry *e = &entries[slot];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) { e->px[2 * r] = v[r].x; e->px[2 * r + 1] = v[r].y; }
+            e->hi = hi; e->lo = lo; e->nb = nb;
+        }
+    }
+    __syncthreads();
+    const uint32_t todo = count;   // workgroup-uniform
+    if (todo != 0) {
+        for (uint32_t first = wave * 8u; first < todo; first += 8u * (SVS_WG / 64)) {
+            const uint32_t idx = first + (lane >> 3);
+            if (idx < todo) guard_replay8<QM>(&entries[idx], &tiles[wave][(lane >> 3) * SVS_GUARD_TILE], lane & 7u, n, qp);
+        }
+        __syncthreads();
+        if (undecided) {
+            const GuardEntry *e = &entries[slot];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) { v[r].x = e->px[2 * r]; v[r].y = e->px[2 * r + 1]; }
+        }
+        if (replay_counter != nullptr && threadIdx.x == 0) atomicAdd(replay_counter, (unsigned long long)todo);
+    }
+    if (write) store_rows<1>(stego + off, g.row_pitch, v);
+}
+
 template <int U, int QM>
 __global__ __launch_bounds__(SVS_WG) void extract_exact_kernel(const uint8_t *__restrict__ gray, const Geometry g,
                                                             const QimParams qp, uint8_t *__restrict__ out,

@@ -25,9 +25,11 @@ MAX_AC = 63
 # Transform mode (include/svsdct.h `flags`):
 #   "fast"   FMA-factored DCT on the coefficient rows the payload touches - contract parity (bits exact,
 #            PSNR within 0.01 dB), HBM-roofline speed.  Default of the device-pointer (throughput) level.
-#   "exact"  pocketfft-identical arithmetic - stego pixels bit-identical to the reference.  Default of the
-#            NumPy level, which the drop-in operator and the video pipelines use (they are I/O bound).
-# SVS_DCT_MODE=fast|exact overrides both defaults.
+#   "exact"  pocketfft-identical arithmetic on every block - stego pixels bit-identical to the reference.
+#   "guarded" the same bit-identical pixels from the guarded kernel (FAST-class speed: the cheap path wherever a rigorous
+#            error bound proves it equals the reference's truncation, the exact arithmetic for the few blocks where it
+#            cannot; n_ac <= 7) - falls back to "exact" kernels where it does not apply.
+# SVS_DCT_MODE=fast|exact|guarded overrides both defaults.
 _ENV_MODE = os.environ.get("SVS_DCT_MODE")
 
 
@@ -37,7 +39,9 @@ def mode_flags(mode, default: str) -> int:
         return 0
     if mode == "exact":
         return native.SVS_EXACT_POCKETFFT
-    raise ValueError(f"unknown transform mode {mode!r} (use 'fast' or 'exact')")
+    if mode == "guarded":
+        return native.SVS_EXACT_GUARDED
+    raise ValueError(f"unknown transform mode {mode!r} (use 'fast', 'exact' or 'guarded')")
 
 
 def host_level_mode() -> str:

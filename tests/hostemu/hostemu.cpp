@@ -63,6 +63,13 @@ void embed_exact_pair_dispatch(Blk &a, Blk &b, uint32_t n, uint32_t nb_a, uint32
 
 bool g_constant_shortcut = false;   // exact == 3: constant blocks take forward_exact_paired_constant, as the replay kernel does
 
+// GUARDED (exact == 4, one coefficient row): -> true when the block has to be redone with the exact arithmetic
+bool embed_guarded_dispatch(Blk &raw, uint32_t n, uint32_t nb, uint32_t hi, uint32_t lo, const svs::QimParams &qp, int qm) {
+    if (qm == svs::QM_DOUBLE) return svs::embed_block_guarded<svs::QM_DOUBLE>(raw.x, raw.y, n, nb, hi, lo, qp);
+    if (qm == svs::QM_POW2) return svs::embed_block_guarded<svs::QM_POW2>(raw.x, raw.y, n, nb, hi, lo, qp);
+    return svs::embed_block_guarded<svs::QM_F32>(raw.x, raw.y, n, nb, hi, lo, qp);
+}
+
 void embed_exact_dispatch(Blk &raw, uint32_t n, uint32_t nb, uint32_t hi, uint32_t lo, const svs::QimParams &qp, int qm) {
     bool constant = g_constant_shortcut;
     for (int r = 0; r < 8 && constant; ++r)
@@ -113,6 +120,11 @@ uint64_t emu_embed(const uint8_t *gray, uint8_t *stego, int F, int H, int W, dou
     if (!(delta > 0.0) || n == 0) use = 0;
     svs::QimParams qp;
     const int dbl = make_qim(use ? delta : 1.0, &qp);
+    // exact == 4: GUARDED - the cheap path wherever its error bound decides every pixel, the exact arithmetic elsewhere
+    // (same routing as svs_embed_dev: one coefficient row, delta inside the guard's range; anything else is plain EXACT)
+    const bool guarded = exact == 4 && use > 0 && svs::rows_for(n) == 1 && delta >= SVS_GUARD_DELTA_MIN &&
+                         delta <= SVS_GUARD_DELTA_MAX;
+    if (guarded) svs::make_guard(delta, 1, &qp);
     if (use == 0) {
         if (n_bits > 0) {  // nothing consumed -> every block entered and round-tripped (either mode: svs_embed_dev)
             for (uint64_t gb = 0; gb < total; ++gb) {
@@ -151,7 +163,13 @@ uint64_t emu_embed(const uint8_t *gray, uint8_t *stego, int F, int H, int W, dou
             ++gb;
             continue;
         }
-        if (!exact) {
+        if (guarded) {
+            if (embed_guarded_dispatch(raw, (uint32_t)n, nb, hi, lo, qp, dbl)) {
+                raw.load(p, (size_t)W);
+                embed_exact_dispatch(raw, (uint32_t)n, nb, hi, lo, qp, dbl);
+                if (n_replayed) ++*n_replayed;
+            }
+        } else if (!exact) {
             // FAST: blocks whose change is structurally zero are replayed with the exact arithmetic (the kernels do that in
             // a second pass over a per-block bitmap; csrc/svs_device.hpp "replay")
             if (embed_dispatch(svs::rows_for(n), raw, (uint32_t)n, nb, hi, lo, qp, dbl)) {

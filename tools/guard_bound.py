@@ -1,0 +1,398 @@
+#!/usr/bin/env python3
+"""Rigorous per-block bound behind the GUARDED embed mode (csrc/svs_block.hpp: SVS_GUARD_KDC / _KE / _KD).
+
+Question.  The reference transforms a block forth and back in float32 (pocketfft; config_and_setup.py:135,166-171):
+
+    D  = pf_dct2(pf_dct2(X, axis 0), axis 1)              X = the 64 integer pixels, 0..255
+    D' = D with coefficients k = 1..nb replaced by cn_k = float(q_k * delta)
+    out = pf_dct3(pf_dct3(D', axis 0), axis 1),   pixel = trunc(clip(out, 0, 255))
+
+The guarded kernel predicts `out` WITHOUT the full transforms:  pred = X + G(change),  change_k = fl(cn_k - D_k) for the
+modified k (D_k pocketfft-identical, G = the exact inverse DCT evaluated sparsely), and keeps trunc(clip(pred)) whenever
+pred is farther than BETA from every integer - otherwise the block is redone with the pocketfft-identical arithmetic.
+That is bit-identical to the reference iff  |out - pred| <= BETA  for every pixel.  This script derives BETA as a function
+of three numbers the kernel has per block:  m = mean pixel,  r = ||X - m||_2 (from the sums of p and p^2),  delta.
+
+Method.  Standard first-order running error analysis (Higham, "Accuracy and Stability of Numerical Algorithms", ch. 3):
+every float32 operation returns exact(operands) * (1 + d), |d| <= u = 2^-24 (a stored constant: another such factor), so
+
+    out_o - ideal_o = sum over operations  G[o, op] * d_op * t_op     (+ terms of order u^2, bounded at the end)
+
+where t_op is the operation's IDEAL result (real arithmetic, real cosines: a linear form in the pixels and in the
+coefficient changes) and G[o, op] the exact linear gain from that operation to output pixel o.  Both are obtained by
+recording svs::pf::dct2_8 / dct3_8 operation by operation on a tape (forward values) and sweeping it backwards (gains).
+Operations on integers below 2^24 (the first stages on pixels) and products by powers of two are exact: d = 0.
+With X = m * 1 + R (R has zero mean), t_op = m * s_op + w_op . R + wd_op . Delta, hence for every pixel o
+
+    |out_o - ideal_o| <= u * [ m * sum |G| |s_op|  +  sum |G| |w_op . R|  +  dmax * sum |G| ||wd_op||_1 ]
+                       = u * [ m * KDC(o)          +  ||M_o R||_1         +  dmax * KD(o) ]
+
+and ||M_o R||_1 <= KE(o) * ||R||_2 with KE(o) an upper bound on the (2 -> 1) operator norm of M_o (rows G[o,op] * w_op
+with their mean removed).  KE is bounded by weighted Cauchy-Schwarz:  for ANY positive weights c,
+||M R||_1 = sum c_i |m_i . R| / c_i <= sqrt(sum c_i^2) * sigma_max(diag(1/c) M) * ||R||_2;  the script improves c by a
+few reweighting steps and keeps the best value (every c gives a valid bound; a lower bound from a sign iteration is
+printed next to it to show how tight it is).
+
+What is compared: ideal_o = X_o + G(Delta)_o with Delta_k := cn_k - c_k(ideal).  The kernel's change_k = fl(cn_k - D_k)
+differs from Delta_k by the forward error of D_k and one rounding; since `out` carries the forward errors of the
+UNmodified coefficients and pred those of the modified ones (with opposite sign), out - pred sees the forward errors of
+ALL coefficients through the ideal inverse - so the gains of forward operations are taken through the full ideal inverse
+whatever the modified set is, and KDC / KE do not depend on n.  Only KD (intermediates of the inverse that carry the
+coefficient changes; plus the kernel's own sparse inverse) depends on the number of modified coefficients.
+
+Output: constants for  BETA = u' * (KDC * m + KE * r + KD * 1.5 delta) + tiny,  u' = 2^-24 (1 + 2^-10) (second-order terms).
+`--check N`: N random blocks per content class through float32 scipy (the reference's own arithmetic) - the observed
+|out - pred| must stay below the bound; the ratio shows its slack.
+"""
+import argparse
+import math
+
+import numpy as np
+
+U32 = 2.0 ** -24
+NPIX = 64
+NSYM = 64 + 63          # pixels, then Delta_1..Delta_63 (index 64 + k - 1)
+
+
+class Tape:
+    def __init__(self):
+        self.w = []        # ideal linear form of every node
+        self.deps = []     # [(real coefficient, operand index)]
+        self.kappa = []    # number of relative errors <= u attached to |ideal value| (0 = exact operation)
+        self.is_int = []
+
+    def node(self, w, deps, kappa, is_int=False):
+        self.w.append(w)
+        self.deps.append(deps)
+        self.kappa.append(kappa)
+        self.is_int.append(is_int)
+        return len(self.w) - 1
+
+    def inp(self, w, is_int=False):
+        return self.node(w, [], 0, is_int)
+
+    def _int_exact(self, w, a, b):
+        if not (self.is_int[a] and self.is_int[b]):
+            return False
+        p = w[:64]
+        return 255.0 * max(p[p > 0].sum(), -p[p < 0].sum()) < 2 ** 24
+
+    def add(self, a, b, sign=1.0):
+        w = self.w[a] + sign * self.w[b]
+        ex = self._int_exact(w, a, b)
+        return self.node(w, [(1.0, a), (sign, b)], 0 if ex else 1, ex)
+
+    def sub(self, a, b):
+        return self.add(a, b, -1.0)
+
+    def mul_pow2(self, a, c):
+        return self.node(self.w[a] * c, [(c, a)], 0, self.is_int[a] and float(c).is_integer())
+
+    def mulc(self, a, c_real):
+        """fl(a * c_float): representation error of the constant + the rounding of the product"""
+        return self.node(self.w[a] * c_real, [(c_real, a)], 2)
+
+    def fma2(self, sign2, a, b):
+        """fl(+-2 a + b): the product by 2 is exact, one rounding"""
+        w = sign2 * 2.0 * self.w[a] + self.w[b]
+        ex = self._int_exact(w, a, b)
+        return self.node(w, [(sign2 * 2.0, a), (1.0, b)], 0 if ex else 1, ex)
+
+
+TW = [math.cos((i + 1) * math.pi / 16) for i in range(7)]
+WQ = math.cos(math.pi / 4)
+SQRT2 = math.sqrt(2.0)
+
+
+def pf_dct2(t, x):
+    """svs::pf::dct2_8, operation for operation (csrc/svs_block.hpp)"""
+    c = [None] * 8
+    c[0] = t.mul_pow2(x[0], 2.0)
+    c[7] = t.mul_pow2(x[7], 2.0)
+    for k in (1, 3, 5):
+        c[k + 1] = t.sub(x[k + 1], x[k])
+        c[k] = t.add(x[k], x[k + 1])
+    h0, h4 = t.add(c[0], c[7]), t.sub(c[0], c[7])
+    h1, tr2 = t.add(c[1], c[5]), t.sub(c[1], c[5])
+    ti2, h2 = t.add(c[2], c[6]), t.sub(c[2], c[6])
+    h6 = t.add(t.mulc(ti2, WQ), t.mulc(tr2, WQ))
+    h5 = t.sub(t.mulc(tr2, WQ), t.mulc(ti2, WQ))
+    r = [None] * 8
+    a0, b0 = t.fma2(+1, c[3], h0), t.fma2(-1, c[3], h0)
+    r[0], r[4] = t.fma2(+1, h1, a0), t.fma2(-1, h1, a0)
+    r[6], r[2] = t.fma2(+1, h2, b0), t.fma2(-1, h2, b0)
+    a1, b1 = t.fma2(-1, c[4], h4), t.fma2(+1, c[4], h4)
+    r[1], r[5] = t.fma2(+1, h5, a1), t.fma2(-1, h5, a1)
+    r[7], r[3] = t.fma2(+1, h6, b1), t.fma2(-1, h6, b1)
+    X = [None] * 8
+    for (i, j, ia, ib) in ((1, 7, 0, 6), (2, 6, 1, 5), (3, 5, 2, 4)):
+        ra, rb = TW[ia] * 0.125, TW[ib] * 0.125
+        t1 = t.add(t.mulc(r[j], ra), t.mulc(r[i], rb))
+        t2 = t.sub(t.mulc(r[i], ra), t.mulc(r[j], rb))
+        X[i], X[j] = t.add(t1, t2), t.sub(t1, t2)
+    X[4] = t.mulc(r[4], TW[3] * 0.25)
+    X[0] = t.mulc(r[0], SQRT2 * 0.125)
+    return X
+
+
+def pf_dct3(t, X):
+    """svs::pf::dct3_8, operation for operation"""
+    c = [None] * 8
+    c[0] = t.mulc(X[0], SQRT2 * 0.25)
+    for (i, j, ia, ib) in ((1, 7, 0, 6), (2, 6, 1, 5), (3, 5, 2, 4)):
+        ra, rb = TW[ia] * 0.25, TW[ib] * 0.25
+        t1, t2 = t.add(X[i], X[j]), t.sub(X[i], X[j])
+        c[i] = t.add(t.mulc(t2, ra), t.mulc(t1, rb))
+        c[j] = t.sub(t.mulc(t1, ra), t.mulc(t2, rb))
+    c[4] = t.mulc(X[4], TW[3] * 0.5)
+    # rfft8_forward
+    y = [None] * 8
+    for k in range(2):
+        tr1 = t.add(c[k + 6], c[k + 2])
+        y[4 * k + 2] = t.sub(c[k + 6], c[k + 2])
+        tr2 = t.add(c[k], c[k + 4])
+        y[4 * k + 1] = t.sub(c[k], c[k + 4])
+        y[4 * k] = t.add(tr2, tr1)
+        y[4 * k + 3] = t.sub(tr2, tr1)
+    tr2 = t.add(t.mulc(y[5], WQ), t.mulc(y[6], WQ))
+    ti2 = t.sub(t.mulc(y[6], WQ), t.mulc(y[5], WQ))
+    r = [None] * 8
+    r[0], r[7] = t.add(y[0], y[4]), t.sub(y[0], y[4])
+    r[4] = t.mul_pow2(y[7], -1.0)
+    r[3] = y[3]
+    r[1], r[5] = t.add(y[1], tr2), t.sub(y[1], tr2)
+    r[2], r[6] = t.add(ti2, y[2]), t.sub(ti2, y[2])
+    x = [None] * 8
+    x[0], x[7] = r[0], r[7]
+    for k in (1, 3, 5):
+        x[k] = t.sub(r[k], r[k + 1])
+        x[k + 1] = t.add(r[k + 1], r[k])
+    return x
+
+
+def dct_basis():
+    """B[k][pixel]: the ideal orthonormal 2-D basis, k = 8u + v, pixel = 8y + x"""
+    a = lambda u: math.sqrt(1 / 8) if u == 0 else math.sqrt(2 / 8)
+    B = np.zeros((64, 64))
+    for u in range(8):
+        for v in range(8):
+            for y in range(8):
+                for x in range(8):
+                    B[8 * u + v, 8 * y + x] = (a(u) * a(v) * math.cos((2 * y + 1) * u * math.pi / 16) *
+                                               math.cos((2 * x + 1) * v * math.pi / 16))
+    return B
+
+
+def gains(t, seeds):
+    """reverse sweep: seeds = {node: adjoint vector over the 64 outputs}; returns G[node] (n_nodes x 64)"""
+    n = len(t.w)
+    G = np.zeros((n, 64))
+    for idx, s in seeds.items():
+        G[idx] += s
+    for i in range(n - 1, -1, -1):
+        if not G[i].any():
+            continue
+        for (coef, a) in t.deps[i]:
+            G[a] += coef * G[i]
+    return G
+
+
+def build(nb):
+    """tapes of the forward pass (pixels -> D) and of the inverse pass (D' -> out) for nb modified coefficients"""
+    B = dct_basis()
+    tf = Tape()
+    px = []
+    for j in range(64):
+        w = np.zeros(NSYM)
+        w[j] = 1.0
+        px.append(tf.inp(w, True))
+    V = [[None] * 8 for _ in range(8)]
+    for x in range(8):
+        out = pf_dct2(tf, [px[8 * y + x] for y in range(8)])
+        for u in range(8):
+            V[u][x] = out[u]
+    D = [pf_dct2(tf, V[u]) for u in range(8)]
+    for u in range(8):
+        for v in range(8):
+            assert np.allclose(tf.w[D[u][v]][:64], B[8 * u + v], atol=1e-12)
+    # forward operations reach output pixel o through ALL coefficients and the ideal inverse: seed D_k with B[k, :]
+    Gf = gains(tf, {D[u][v]: B[8 * u + v] for u in range(8) for v in range(8)})
+
+    ti = Tape()
+    Dp = [[None] * 8 for _ in range(8)]
+    for u in range(8):
+        for v in range(8):
+            k = 8 * u + v
+            w = np.zeros(NSYM)
+            w[:64] = B[k]
+            if 1 <= k <= nb:
+                w[64 + k - 1] = 1.0
+            Dp[u][v] = ti.inp(w)
+    P = [[None] * 8 for _ in range(8)]             # vertical inverse first (axis 0, config_and_setup.py:168)
+    for v in range(8):
+        out = pf_dct3(ti, [Dp[u][v] for u in range(8)])
+        for y in range(8):
+            P[y][v] = out[y]
+    outs = {}
+    for y in range(8):
+        o = pf_dct3(ti, P[y])
+        for x in range(8):
+            ideal = np.zeros(NSYM)
+            ideal[8 * y + x] = 1.0
+            for k in range(1, nb + 1):
+                ideal[64 + k - 1] = B[k, 8 * y + x]
+            assert np.allclose(ti.w[o[x]], ideal, atol=1e-12)
+            e = np.zeros(64)
+            e[8 * y + x] = 1.0
+            outs[o[x]] = e
+    Gi = gains(ti, outs)
+    return B, tf, Gf, ti, Gi
+
+
+def op_norm_2_to_1(M, iters=12):
+    """upper and lower bound on max ||M R||_1 / ||R||_2"""
+    M = M[np.abs(M).sum(axis=1) > 0]
+    rn = np.linalg.norm(M, axis=1)
+    best = rn.sum()                                   # operation-wise Cauchy-Schwarz
+    c2 = rn.copy()
+    for _ in range(iters):
+        A = (M / c2[:, None]).T @ M                   # M^T diag(1/c^2) M
+        lam, vec = np.linalg.eigh(A)
+        bound = math.sqrt(c2.sum() * lam[-1])
+        best = min(best, bound)
+        v = vec[:, -1]
+        c2 = np.abs(M @ v) + 1e-3 * rn                # reweight towards the maximiser
+    # lower bound: alternate s = sign(M v), v = M^T s / ||.||
+    lo = 0.0
+    rng = np.random.default_rng(0)
+    for _ in range(8):
+        v = rng.standard_normal(M.shape[1])
+        for _ in range(60):
+            s = np.sign(M @ v)
+            v = M.T @ s
+            v /= np.linalg.norm(v)
+        lo = max(lo, np.abs(M @ v).sum())
+    return best * (1 + 1e-9), lo
+
+
+def sparse_inverse_terms(nb, rows):
+    """The kernel's own side of the comparison, per unit of dmax (everything here is proportional to the coefficient
+    changes): change_k = fl(cn_k - D_k) carries one rounding; the sparse inverse (svs::idct8 FMA forms, then the vertical
+    products) performs at most `ops` roundings on the way to a pixel, each of a partial sum that is bounded by the sum of
+    the absolute terms, i.e. by nb * dmax * max|basis product| * 4 (the factor covers unnormalised intermediates)."""
+    ops = 2 * (8 + 2 * rows) + 6
+    return nb * 0.25 + ops * nb * 0.5 * 2.0
+
+
+def analyse(nb, verbose=True):
+    B, tf, Gf, ti, Gi = build(nb)
+    kf = np.array(tf.kappa, dtype=float)
+    ki = np.array(ti.kappa, dtype=float)
+    Wf = np.array(tf.w)
+    Wi = np.array(ti.w)
+    sf = Wf[:, :64].sum(axis=1)                    # response to the all-ones block
+    si = Wi[:, :64].sum(axis=1)
+    Rf = Wf[:, :64] - sf[:, None] / 64.0           # mean-free part (R is orthogonal to the constant)
+    Ri = Wi[:, :64] - si[:, None] / 64.0
+    Di = np.abs(Wi[:, 64:]).sum(axis=1)
+    worst = dict(kdc=0.0, ke=0.0, kd=0.0, ke_lo=0.0)
+    rows = (nb >> 3) + 1
+    for o in range(64):
+        gf = kf * np.abs(Gf[:, o])
+        gi = ki * np.abs(Gi[:, o])
+        kdc = (gf * np.abs(sf)).sum() + (gi * np.abs(si)).sum()
+        kd = (gi * Di).sum() + sparse_inverse_terms(nb, rows)
+        M = np.vstack([Rf * gf[:, None], Ri * gi[:, None]])
+        ke, ke_lo = op_norm_2_to_1(M)
+        worst["kdc"] = max(worst["kdc"], kdc)
+        worst["kd"] = max(worst["kd"], kd)
+        if ke > worst["ke"]:
+            worst["ke"], worst["ke_lo"] = ke, ke_lo
+    if verbose:
+        n_round = int((kf > 0).sum() + (ki > 0).sum())
+        print("nb = %2d: %d rounding operations on the tapes;  KDC = %.3f   KE = %.3f (lower bound %.3f)   KD = %.3f" %
+              (nb, n_round, worst["kdc"], worst["ke"], worst["ke_lo"], worst["kd"]))
+    return worst
+
+
+U_EFF = U32 * (1 + 2.0 ** -10)       # second-order terms: (1 + u)^m - 1 <= m u (1 + 2^-10) for m <= 10^3
+TINY = 2.0 ** -20                    # u * |D_k| representation slack of dmax (|c| <= 2040), cn's own rounding, etc.
+
+
+def beta(k, m, r, delta):
+    return U_EFF * (k["kdc"] * m + k["ke"] * r + k["kd"] * (1.5 * delta + 0.01)) + TINY
+
+
+def empirical(k, n_blocks, n, delta, seed=7):
+    import scipy.fftpack as fp
+    rng = np.random.default_rng(seed)
+    res = []
+    for kind in ("noise16-240", "full", "bright", "dark", "flat", "checker", "ramp", "smooth"):
+        if kind == "noise16-240":
+            blk = rng.integers(16, 240, size=(n_blocks, 8, 8), dtype=np.uint8)
+        elif kind == "full":
+            blk = rng.integers(0, 256, size=(n_blocks, 8, 8), dtype=np.uint8)
+        elif kind == "bright":
+            blk = rng.integers(200, 256, size=(n_blocks, 8, 8), dtype=np.uint8)
+        elif kind == "dark":
+            blk = rng.integers(0, 16, size=(n_blocks, 8, 8), dtype=np.uint8)
+        elif kind == "flat":
+            blk = np.repeat(rng.integers(0, 256, size=(n_blocks, 1, 1), dtype=np.uint8), 64, axis=1).reshape(-1, 8, 8)
+        elif kind == "checker":
+            blk = ((np.indices((8, 8)).sum(0) % 2) * 255).astype(np.uint8)[None].repeat(n_blocks, 0)
+        elif kind == "ramp":
+            blk = (np.arange(64).reshape(8, 8) * 4).astype(np.uint8)[None].repeat(n_blocks, 0)
+        else:
+            base = rng.integers(20, 230, size=(n_blocks, 1, 1))
+            gx = rng.integers(-3, 4, size=(n_blocks, 1, 1)) * np.arange(8)[None, None, :]
+            gy = rng.integers(-3, 4, size=(n_blocks, 1, 1)) * np.arange(8)[None, :, None]
+            blk = np.clip(base + gx + gy + rng.integers(-2, 3, size=(n_blocks, 8, 8)), 0, 255).astype(np.uint8)
+        X = blk.astype(np.float32)
+        D = fp.dct(fp.dct(X, axis=1, norm="ortho"), axis=2, norm="ortho")
+        flat = D.reshape(-1, 64)
+        bits = rng.integers(0, 2, size=(len(X), n))
+        chg = np.zeros((len(X), 64), dtype=np.float32)
+        for i in range(n):
+            kk = i + 1
+            c = flat[:, kk].copy()
+            q = np.rint(c / np.float32(delta)).astype(np.int64)
+            q = q + bits[:, i] - (q & 1)
+            cn = (q * float(delta)).astype(np.float32)
+            chg[:, kk] = cn - c                           # float32 subtraction, as the kernel does
+            flat[:, kk] = cn
+        out = fp.idct(fp.idct(D, axis=1, norm="ortho"), axis=2, norm="ortho").astype(np.float64)
+        pred = blk.astype(np.float64) + fp.idct(fp.idct(chg.astype(np.float64).reshape(-1, 8, 8), axis=1, norm="ortho"),
+                                                axis=2, norm="ortho")
+        err = np.abs(out - pred).reshape(len(X), -1).max(axis=1)
+        p = blk.reshape(len(X), -1).astype(np.float64)
+        m = p.mean(axis=1)
+        r = np.sqrt(((p - m[:, None]) ** 2).sum(axis=1))
+        b = beta(k, m, r, delta)
+        assert (err <= b).all(), (kind, float((err / b).max()))
+        res.append((kind, float(err.max()), float(b.mean()), float((b / np.maximum(err, 1e-12)).min())))
+    return res
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--check", type=int, default=0, help="random blocks per content class for the empirical comparison")
+    args = ap.parse_args()
+    ks = {}
+    for nb in (0, 3, 7, 10, 15, 63):
+        ks[nb] = analyse(nb)
+    for rows, nmax in ((1, 7), (2, 15), (8, 63)):
+        k = ks[nmax]
+        print("U = %d (n <= %2d):  BETA = %.6e * (%.4f * mean + %.4f * resid_l2 + %.3f * 1.5 delta) + 2^-20" %
+              (rows, nmax, U_EFF, k["kdc"], k["ke"], k["kd"]))
+        print("     mid-gray noise block (mean 128, resid 517), delta 8:  BETA = %.3e;  flat 128: %.3e;  smooth (resid 40): %.3e"
+              % (beta(k, 128, 517, 8), beta(k, 128, 0, 8), beta(k, 128, 40, 8)))
+    if args.check:
+        for (n, delta) in ((3, 8), (7, 8), (3, 100), (10, 8), (15, 20)):
+            k = ks[7] if n <= 7 else ks[15]
+            for (kind, emax, bmean, slack) in empirical(k, args.check, n, delta):
+                print("  n = %2d delta = %3d %-12s max |out - pred| = %.3e   mean BETA = %.3e   min BETA/err = %.1f" %
+                      (n, delta, kind, emax, bmean, slack))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,101 @@
+#!/usr/bin/env python3
+"""GUARDED embed on the GPU: byte-identity with the EXACT kernel, share of blocks redone exactly, kernel time next to
+FAST and EXACT - per content class.  usage: python tools/guarded_probe.py [--frames 200] [--n-ac 3] [--delta 8]
+Frames are 3840x2160 device-resident; times are HIP events on the launch stream, median of 7 after 2 warm-ups."""
+import argparse, ctypes as C, json, os, statistics, sys
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(REPO, "secure-video-steganography-using-ecc-and-dct_amd"))
+import torch
+from svsdct import batch, native
+from svsdct.native import Planes
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--frames", type=int, default=200)
+ap.add_argument("--n-ac", type=int, default=3)
+ap.add_argument("--delta", type=float, default=8.0)
+ap.add_argument("--h", type=int, default=2160)
+ap.add_argument("--w", type=int, default=3840)
+ap.add_argument("--classes", default="noise,natural,flat128,flat16,letterbox25,rows,columns,checker8,dark,bright")
+ap.add_argument("--json", default="")
+a = ap.parse_args()
+F, H, W, n, delta = a.frames, a.h, a.w, a.n_ac, a.delta
+lib = native.load(); native.ensure_device(0)
+lib.svs_guard_counter_set.restype = C.c_int; lib.svs_guard_counter_set.argtypes = [C.c_void_p]
+dev = torch.device("cuda", 0)
+planes = Planes.contiguous(F, H, W)
+cap = batch.capacity_bits(F, H, W, n); nbytes = (cap + 7) // 8
+blocks = F * (H // 8) * (W // 8)
+gray = torch.empty((F, H, W), dtype=torch.uint8, device=dev)
+stego = {m: torch.empty_like(gray) for m in ("exact", "guarded")}
+pay = torch.zeros(nbytes + 8, dtype=torch.uint8, device=dev)
+counter = torch.zeros(1, dtype=torch.int64, device=dev)
+st = torch.cuda.current_stream().cuda_stream
+lib.svs_fill_bits_dev(pay.data_ptr(), cap, 1, 0, st)
+
+
+def content(kind):
+    lib.svs_fill_synthetic_dev(gray.data_ptr(), C.byref(planes), 7, 0, 16, 224, st)
+    if kind == "noise":
+        return
+    if kind == "natural":      # smooth gradients + mild texture: low-pass the noise and add a ramp
+        g = gray[:, ::8, ::8].float()
+        up = torch.nn.functional.interpolate(g[:, None], size=(H, W), mode="bilinear", align_corners=False)[:, 0]
+        tex = (gray.float() - 128.0) * 0.06
+        ramp = torch.linspace(-30, 30, W, device=dev)[None, None, :]
+        gray.copy_((up * 0.6 + 50 + tex + ramp).clamp(0, 255).to(torch.uint8))
+    elif kind == "flat128":
+        gray.fill_(128)
+    elif kind == "flat16":
+        gray.fill_(16)
+    elif kind == "letterbox25":
+        gray[:, : H // 8, :] = 16; gray[:, H - H // 8:, :] = 16
+    elif kind == "rows":
+        gray.copy_(gray[:, :, :1].expand(F, H, W).contiguous())
+    elif kind == "columns":
+        gray.copy_(gray[:, :1, :].expand(F, H, W).contiguous())
+    elif kind == "checker8":
+        yy = (torch.arange(H, device=dev) // 8)[:, None]; xx = (torch.arange(W, device=dev) // 8)[None, :]
+        gray.copy_((((yy + xx) % 2) * 200 + 20).to(torch.uint8)[None].expand(F, H, W))
+    elif kind == "dark":
+        gray.copy_(gray // 64)
+    elif kind == "bright":
+        gray.copy_(252 + gray // 64)
+    else:
+        raise SystemExit(f"unknown class {kind}")
+
+
+def timed(mode, out):
+    ts = []
+    for _ in range(9):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        batch.embed_device(gray.data_ptr(), out.data_ptr(), planes, delta, n, pay.data_ptr(), 0, cap, st, mode=mode)
+        e1.record(); torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1))
+    return statistics.median(ts[2:])
+
+
+rows = []
+print(f"{F} x {W}x{H}, n = {n}, delta = {delta:g}: ms per embed call (median of 7); algorithmic bytes per call "
+      f"{2 * F * H * W + nbytes:,}")
+for kind in a.classes.split(","):
+    content(kind)
+    torch.cuda.synchronize()
+    t_exact = timed("exact", stego["exact"])
+    lib.svs_guard_counter_set(None)
+    t_guard = timed("guarded", stego["guarded"])
+    counter.zero_(); lib.svs_guard_counter_set(counter.data_ptr())
+    batch.embed_device(gray.data_ptr(), stego["guarded"].data_ptr(), planes, delta, n, pay.data_ptr(), 0, cap, st, mode="guarded")
+    torch.cuda.synchronize(); lib.svs_guard_counter_set(None)
+    redone = int(counter.item())
+    same = bool(torch.equal(stego["exact"], stego["guarded"]))
+    ndiff = 0 if same else int((stego["exact"] != stego["guarded"]).sum().item())
+    t_fast = timed("fast", stego["guarded"])
+    gbs = (2 * F * H * W + nbytes) / (t_guard * 1e-3) / 1e9
+    rows.append(dict(content=kind, exact_ms=t_exact, guarded_ms=t_guard, fast_ms=t_fast, redone_share=redone / blocks,
+                     identical=same, differing_pixels=ndiff, guarded_gbs=gbs))
+    print(f"  {kind:12s} exact {t_exact:7.3f}  guarded {t_guard:7.3f} ({gbs:6.0f} GB/s)  fast {t_fast:7.3f}   redone exactly "
+          f"{100.0 * redone / blocks:6.2f} %   guarded == exact: {same}" + ("" if same else f"  ({ndiff} pixels differ)"))
+if a.json:
+    with open(a.json, "w") as fh:
+        json.dump(dict(frames=F, height=H, width=W, n_ac=n, delta=delta, rows=rows), fh, indent=1)
