@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define SVS_ABI_VERSION 2
+#define SVS_ABI_VERSION 3
 
 #define SVS_OK 0
 #define SVS_ERR_INVALID_ARG (-1)  /* bad geometry / NULL pointer / size overflow */
@@ -51,31 +51,36 @@ extern "C" {
 #define SVS_ERR_CAPACITY (-4)     /* an output buffer is too small */
 
 /* `flags` of the embed / extract entry points.
- *   0                  FAST: an FMA-factored float32 DCT restricted to the coefficient rows the payload touches, at
- *                      HBM-roofline speed, with the two places where float32 noise of the reference's own transform
- *                      decides the outcome sent through the exact arithmetic below:
- *                        - embed: a block whose coefficient changes are structurally zero (flat areas, letterbox bars,
- *                          one-dimensional structure; config_and_setup.py:166-171 round-trips such a block and truncates
- *                          x - 1e-5 to x - 1) is redone by a second, small launch (embed_replay_kernel);
- *                        - extract: a block with a quantiser input within a proven error bound of a rounding tie is
- *                          recomputed inside the kernel with the pocketfft-identical transform.
- *                      Result: extracted bits identical to the reference's for ANY input frame; stego PSNR within
- *                      0.01 dB of the reference's on any content (measured <= 0.006 dB, tests/test_gpu_parity.py).
- *                      Stego pixels can still differ from the reference's where float32 noise decides a single
- *                      pixel's floor or a quantiser near-tie (about 1e-5 of the pixels at n = 3, 1e-3 at n = 10).
- *   SVS_EXACT_POCKETFFT  every float32 operation of scipy.fftpack.dct/idct(norm='ortho') (pocketfft) is
- *                      replayed in order, on all 64 coefficients: stego pixels, tie decisions and the
- *                      reference's round-trip artefacts are bit-identical to the reference.  About 2.5x the
- *                      arithmetic: VALU-bound. */
+ * All modes run ONE streaming embed kernel shape (csrc/svs_device.hpp): every block goes HBM -> registers -> HBM once,
+ * computed with a cheap sparse transform; a block whose result the float32 round-trip noise of the reference's own
+ * transform could decide (config_and_setup.py:166-171 transforms every block forth and back and truncates: x - 1e-5
+ * becomes x - 1) is "undecided" and is redone INSIDE the kernel with the pocketfft-identical arithmetic (eight lanes per
+ * block, LDS worklist private to the wave) - no second launch, no scratch memory, no state kept between calls: every
+ * entry point is re-entrant and thread-safe.
+ *   0                  FAST.  n_ac <= 7: identical to SVS_EXACT_GUARDED (the same launch).  n_ac >= 8: FMA-factored
+ *                      float32 DCT on the coefficient rows the payload touches; a block is undecided when any pixel's
+ *                      predicted value lies within 2^-13 of an integer (the largest round-trip noise observed on 10^7
+ *                      blocks of every content class is 1.3e-4, tools/guard_bound.py --check).  Extraction: bits
+ *                      identical to the reference's for ANY input frame (n_ac <= 7: pocketfft-identical transform;
+ *                      n_ac >= 8: a block with a quantiser input within a proven error bound of a rounding tie is
+ *                      recomputed with it).  Contract for n_ac >= 8: extracted bits exact, stego PSNR within 0.01 dB of
+ *                      the reference's on any content; pixels can differ where the two forward transforms resolve a
+ *                      quantiser near-tie differently (about 1e-3 of the pixels at n = 10).
+ *   SVS_EXACT_POCKETFFT  every float32 operation of scipy.fftpack.dct/idct(norm='ortho') (pocketfft) is replayed in
+ *                      order, on all 64 coefficients of every block, one lane per block: stego pixels, tie decisions
+ *                      and the reference's round-trip artefacts are bit-identical to the reference.  About 5x the
+ *                      arithmetic of FAST: VALU-bound (0.42 of the HBM roofline).  The yardstick the other modes are
+ *                      tested against.
+ *   SVS_EXACT_GUARDED  the same bit-identical result at streaming speed: the kernel computes the payload coefficients
+ *                      exactly as pocketfft does (every quantiser decision is the reference's), predicts each stego
+ *                      pixel from the sparse inverse of the coefficient changes, and keeps the prediction only where a
+ *                      RIGOROUS per-block bound on the reference's round-trip noise (tools/guard_bound.py: running
+ *                      error analysis of every pocketfft operation; BETA = u (17 mean + 39.4 ||block - mean||_2 +
+ *                      197 * 1.5 delta)) proves the truncation cannot differ; the 0.3 - 2.5 % of blocks it cannot
+ *                      decide (12.5 % of flat blocks at n = 3) are redone exactly.  Applies to n_ac <= 7 and
+ *                      0.25 <= delta <= 4096; other calls run the SVS_EXACT_POCKETFFT kernels, so the flag is always
+ *                      safe to pass and always bit-identical.  Default of the drop-in operator and video pipelines. */
 #define SVS_EXACT_POCKETFFT 1u
-/*   SVS_EXACT_GUARDED  the same bit-identical result as SVS_EXACT_POCKETFFT, obtained at (nearly) FAST speed: the embed
- *                      kernel computes the payload coefficients exactly as pocketfft does, predicts every stego pixel
- *                      from the sparse inverse of the coefficient changes, and keeps that prediction only where a
- *                      rigorous per-block bound on the reference's float32 round-trip noise (tools/guard_bound.py)
- *                      proves the truncation cannot differ; the few per cent of blocks it cannot decide are redone
- *                      inside the same kernel with the pocketfft-identical arithmetic.  Applies to n_ac <= 7 and
- *                      0.25 <= delta <= 4096; other calls (and extraction) run the SVS_EXACT_POCKETFFT kernels, so the
- *                      flag is always safe to pass. */
 #define SVS_EXACT_GUARDED 2u
 
 /* Geometry of a batch of gray planes. */
@@ -130,9 +135,8 @@ uint64_t svs_packed_bytes(uint64_t n_bits);
  *   n_embedded   : (host) receives min(n_bits, capacity); 0 when delta <= 0 or n_ac <= 0.
  * delta <= 0 or n_ac <= 0: nothing can be embedded; as in the reference every block is still transformed forth and
  * back when n_bits > 0 (config_and_setup.py:143-145,166-169) - both modes run the exact arithmetic for that.
- * Scratch: FAST keeps one small replay map per (device, stream) inside the library (1 bit per block of the largest
- * batch seen on that stream; released by svs_stream_destroy).  Calls on one stream are ordered; concurrent calls must
- * use different streams.
+ * No scratch memory and no state between calls: concurrent calls from several host threads or on several streams are
+ * independent (work on one stream is ordered as usual).
  */
 int svs_embed_dev(const uint8_t *d_gray, uint8_t *d_stego, const svs_planes *planes,
                   double delta, int n_ac,

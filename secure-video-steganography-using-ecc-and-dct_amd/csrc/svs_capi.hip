@@ -146,22 +146,21 @@ Tuning extract_tuning(int rows, const svs_planes *p, const void *a) {
 uint32_t embed_wg_per_cu(int rows, int bpl) { (void)bpl; return rows == 1 ? 5u : 0u; }
 uint32_t extract_wg_per_cu(int rows) { (void)rows; return 0; }
 
-// 64-bit words of the replay map an embed launch over `total` blocks writes (one per wave and block-of-the-lane)
-uint64_t replay_map_words(uint64_t total, int bpl) {
-    const uint64_t grid = (total + SVS_WG * bpl - 1) / (SVS_WG * bpl);
-    return grid * (SVS_WG / 64) * bpl;
-}
+unsigned long long *g_guard_counter = nullptr;   // measurement hook (svs_guard_counter_set): blocks redone exactly
+
+// static LDS of embed_kernel: the waves' worklists and transposition tiles
+constexpr uint32_t kEmbedLds = (SVS_WG / 64) * (SVS_GUARD_CAP * sizeof(svs::GuardEntry) + 8 * SVS_GUARD_TILE * sizeof(float));
 
 template <int QM, int BPL>
 int launch_embed(int rows, uint64_t total, hipStream_t st, const uint8_t *gray, uint8_t *stego, const svs::Geometry &g,
                  const svs::QimParams &qp, const uint32_t *bits, uint64_t bit_offset, uint64_t n_bits,
-                 uint32_t n_words, uint64_t *replay_map) {
+                 uint32_t n_words) {
     const dim3 grid((uint32_t)((total + SVS_WG * BPL - 1) / (SVS_WG * BPL)));
-    const uint32_t lds_pad = lds_pad_for(env_chunk("SVS_EMBED_WG_PER_CU", embed_wg_per_cu(rows, BPL)), 0);
+    const uint32_t lds_pad = lds_pad_for(env_chunk("SVS_EMBED_WG_PER_CU", embed_wg_per_cu(rows, BPL)), kEmbedLds);
 #define SVS_CASE(R)                                                                                            \
     case R:                                                                                                    \
         hipLaunchKernelGGL((svs::embed_kernel<R, QM, BPL>), grid, dim3(SVS_WG), lds_pad, st, gray, stego, g, qp, bits, \
-                           bit_offset, n_bits, n_words, replay_map);                                           \
+                           bit_offset, n_bits, n_words, g_guard_counter);                                      \
         break;
     if constexpr (BPL == 2) {  // two blocks per lane is only instantiated (and only pays) for one coefficient row
         switch (rows) {
@@ -177,69 +176,6 @@ int launch_embed(int rows, uint64_t total, hipStream_t st, const uint8_t *gray, 
 #undef SVS_CASE
     SVS_HIP(hipGetLastError());
     return SVS_OK;
-}
-
-// second pass of a FAST embed: redo the blocks marked in the replay map with the exact arithmetic (svs_device.hpp)
-int launch_embed_replay(int qm, hipStream_t st, const uint8_t *gray, uint8_t *stego, const svs::Geometry &g,
-                        const svs::QimParams &qp, const uint32_t *bits, uint64_t bit_offset, uint64_t n_bits,
-                        uint32_t n_words, uint64_t *replay_map, uint64_t map_words) {
-    const dim3 grid(svs::replay_grid(map_words));
-#define SVS_GO(QM)                                                                                                     \
-    hipLaunchKernelGGL((svs::embed_replay_kernel<QM>), grid, dim3(SVS_REPLAY_WG), 0, st, gray, stego, g, qp, bits, bit_offset, \
-                       n_bits, n_words, replay_map, (uint32_t)map_words)
-    if (qm == svs::QM_DOUBLE) SVS_GO(svs::QM_DOUBLE);
-    else if (qm == svs::QM_POW2) SVS_GO(svs::QM_POW2);
-    else SVS_GO(svs::QM_F32);
-#undef SVS_GO
-    SVS_HIP(hipGetLastError());
-    return SVS_OK;
-}
-
-// The replay map of a stream (svs_device.hpp "REPLAY MAP"): owned by the library, one per (device, stream), grown on
-// demand, zeroed when allocated and kept all-zero between calls by embed_replay_kernel.  Work on one stream is ordered, so
-// calls on the same stream share it safely; different streams have different maps.
-struct ReplayMap {
-    uint64_t *p = nullptr;
-    size_t words = 0;
-};
-std::mutex g_maps_mutex;
-std::map<std::pair<int, hipStream_t>, ReplayMap> g_maps;
-
-int replay_map_for(hipStream_t st, uint64_t words, uint64_t **out) {
-    int dev = 0;
-    SVS_HIP(hipGetDevice(&dev));
-    std::lock_guard<std::mutex> lock(g_maps_mutex);
-    ReplayMap &m = g_maps[std::make_pair(dev, st)];
-    if (m.words < words) {
-        if (m.p) {
-            SVS_HIP(hipStreamSynchronize(st));   // nothing may still be using the old one
-            (void)hipFree(m.p);
-            m = ReplayMap();
-        }
-        const size_t want = (size_t)(words + words / 4 + 1024);
-        void *p = nullptr;
-        SVS_HIP(hipMalloc(&p, want * sizeof(uint64_t)));
-        if (hipMemsetAsync(p, 0, want * sizeof(uint64_t), st) != hipSuccess) {
-            (void)hipFree(p);
-            return fail(SVS_ERR_HIP, "hipMemsetAsync of the replay map failed");
-        }
-        m.p = reinterpret_cast<uint64_t *>(p);
-        m.words = want;
-    }
-    *out = m.p;
-    return SVS_OK;
-}
-
-// after a failed launch the map may hold stale bits: drop it, the next call gets a fresh zeroed one
-void replay_map_discard(hipStream_t st) {
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return;
-    std::lock_guard<std::mutex> lock(g_maps_mutex);
-    auto it = g_maps.find(std::make_pair(dev, st));
-    if (it == g_maps.end()) return;
-    (void)hipStreamSynchronize(st);
-    (void)hipFree(it->second.p);
-    g_maps.erase(it);
 }
 
 template <int QM, int BPL>
@@ -325,27 +261,6 @@ int launch_embed_exact(int qm, uint64_t total, hipStream_t st, const uint8_t *gr
     return SVS_OK;
 }
 
-// GUARDED embed (svs_device.hpp): one launch, bit-identical to launch_embed_exact
-unsigned long long *g_guard_counter = nullptr;   // measurement hook (svs_guard_counter_set): blocks redone exactly
-
-int launch_embed_guarded(int qm, uint64_t total, hipStream_t st, const uint8_t *gray, uint8_t *stego, const svs::Geometry &g,
-                         const svs::QimParams &qp, const uint32_t *bits, uint64_t bit_offset, uint64_t n_bits,
-                         uint32_t n_words) {
-    const dim3 grid((uint32_t)((total + SVS_WG - 1) / SVS_WG));
-    // the kernel's own LDS (worklist + transposition tiles, 29.7 KB) already limits a CU to five workgroups - the occupancy
-    // the streaming embed kernels are fastest at (profiles/r01_ab_occupancy.txt); SVS_EMBED_WG_PER_CU lowers it further
-    const uint32_t lds_pad = lds_pad_for(env_chunk("SVS_EMBED_WG_PER_CU", 0), 29712);
-#define SVS_GO(QM)                                                                                                       \
-    hipLaunchKernelGGL((svs::embed_guarded_kernel<QM>), grid, dim3(SVS_WG), lds_pad, st, gray, stego, g, qp, bits, bit_offset, \
-                       n_bits, n_words, g_guard_counter)
-    if (qm == svs::QM_DOUBLE) SVS_GO(svs::QM_DOUBLE);
-    else if (qm == svs::QM_POW2) SVS_GO(svs::QM_POW2);
-    else SVS_GO(svs::QM_F32);
-#undef SVS_GO
-    SVS_HIP(hipGetLastError());
-    return SVS_OK;
-}
-
 template <int QM>
 int launch_extract_exact(int rows, uint64_t total, hipStream_t st, const uint8_t *gray, const svs::Geometry &g,
                          const svs::QimParams &qp, uint8_t *out, uint64_t out_bytes) {
@@ -374,18 +289,17 @@ struct DevBuf {  // RAII for the host-pointer entry points
 template <int QM, bool EXACT>
 int launch_embed_bgr(int rows, uint64_t total, hipStream_t st, const uint8_t *in, uint8_t *out, uint8_t *ref,
                             const svs::Geometry &g, const svs::ColourParams &c, const svs::QimParams &qp,
-                            const uint32_t *bits, uint64_t bit_offset, uint64_t n_bits, uint32_t n_words,
-                            uint64_t *replay_map) {
+                            const uint32_t *bits, uint64_t bit_offset, uint64_t n_bits, uint32_t n_words) {
     const dim3 grid((uint32_t)((total + SVS_WG - 1) / SVS_WG));
     const uint32_t lds_pad = lds_pad_for(env_chunk("SVS_EMBED_BGR_WG_PER_CU", 0), 16384);
     if constexpr (EXACT) {
         hipLaunchKernelGGL((svs::embed_bgr_kernel<8, QM, true>), grid, dim3(SVS_WG), lds_pad, st, in, out, ref, g, c, qp, bits,
-                           bit_offset, n_bits, n_words, nullptr);
+                           bit_offset, n_bits, n_words);
     } else {
 #define SVS_CASE(R)                                                                                                   \
     case R:                                                                                                           \
         hipLaunchKernelGGL((svs::embed_bgr_kernel<R, QM, false>), grid, dim3(SVS_WG), lds_pad, st, in, out, ref, g, c, qp, bits, \
-                           bit_offset, n_bits, n_words, replay_map);                                                  \
+                           bit_offset, n_bits, n_words);                                                              \
         break;
         switch (rows) {
             SVS_CASE(1) SVS_CASE(2) SVS_CASE(3) SVS_CASE(4) SVS_CASE(5) SVS_CASE(6) SVS_CASE(7) SVS_CASE(8)
@@ -478,7 +392,6 @@ int svs_stream_create(void **stream) {
 }
 
 int svs_stream_destroy(void *stream) {
-    replay_map_discard((hipStream_t)stream);   // the stream's replay map goes with it
     SVS_HIP(hipStreamDestroy((hipStream_t)stream));
     return SVS_OK;
 }
@@ -529,36 +442,31 @@ int svs_embed_dev(const uint8_t *d_gray, uint8_t *d_stego, const svs_planes *pla
     svs::QimParams qp;
     const int qm = make_qim(use == 0 ? 1.0 : delta, &qp);
     if (flags & ~(SVS_EXACT_POCKETFFT | SVS_EXACT_GUARDED)) return fail(SVS_ERR_INVALID_ARG, "unknown flags 0x%x", flags);
-    // SVS_EXACT_GUARDED: the reference's pixels through the guarded kernel where it applies (one coefficient row, something
-    // to embed, delta inside the range its error bound is useful for) - everything else takes the plain exact kernels below
-    if ((flags & SVS_EXACT_GUARDED) && use > 0 && rows_for(n) == 1 && delta >= SVS_GUARD_DELTA_MIN &&
-        delta <= SVS_GUARD_DELTA_MAX && env_chunk("SVS_GUARDED_OFF", 0) == 0) {
-        const uint64_t words_g = ((bit_offset + use + 7) / 8 + 3) / 4;
-        if (words_g >= (1ull << 32)) return fail(SVS_ERR_INVALID_ARG, "payload too large for one call");
-        svs::make_guard(delta, 1, &qp);
-        g.xcd_chunk = env_chunk("SVS_EMBED_XCD_CHUNK", kEighth);
-        if (int rc = launch_embed_guarded(qm, total, st, d_gray, d_stego, g, qp,
-                                          reinterpret_cast<const uint32_t *>(d_bits_packed), bit_offset, use,
-                                          (uint32_t)words_g))
-            return rc;
-        if (n_embedded) *n_embedded = use;
-        return SVS_OK;
-    }
-    if (flags & SVS_EXACT_GUARDED) flags = SVS_EXACT_POCKETFFT;
+    const int rows = rows_for(n);
+    // Which kernel family (include/svsdct.h `flags`).  The streaming kernel (embed_kernel: cheap arithmetic + in-kernel exact
+    // replay of the blocks it cannot decide) serves FAST for any n and, with one coefficient row, GUARDED as well - there its
+    // guard is the rigorous error bound and the output is the reference's bit for bit, so both flags run the same launch.
+    // Outside the delta range the guard is useless (every block undecided below, BETA > 1/8 above): exact kernels.
+    const bool in_range = delta >= SVS_GUARD_DELTA_MIN && delta <= SVS_GUARD_DELTA_MAX;
+    bool streaming = use > 0 && in_range && !(flags & SVS_EXACT_POCKETFFT) && (rows == 1 || !(flags & SVS_EXACT_GUARDED));
+    if ((flags & SVS_EXACT_GUARDED) && env_chunk("SVS_GUARDED_OFF", 0) != 0) streaming = false;   // A/B knob
     // SVS_EXACT_BPL=2 (experiment knob): exact arithmetic on two adjacent blocks per lane with every transform instruction
     // packed over the pair (embed_exact_pair_kernel).  Measured SLOWER than the one-block kernel (3.54 vs 3.16 ms at n = 3,
     // 4.83 vs 3.38 ms at n = 10, profiles/r02_ab_exact_pair.txt): a v_pk_*_f32 costs two issue slots on this chip, so
     // halving the instruction count buys nothing and the 256-register footprint costs occupancy.  Off by default.
     const bool exact_pair = rows_allow_two_blocks(planes, d_gray, d_stego) && env_chunk("SVS_EXACT_BPL", 1) == 2;
-    if (flags & SVS_EXACT_POCKETFFT) {
+    if (!streaming) {
+        if (use == 0 && n_bits == 0) {   // empty payload: the reference's loops break before the first block - a pure copy
+            if (d_gray == d_stego) return SVS_OK;
+            g.n_ac = 1;
+            return two ? launch_embed<svs::QM_F32, 2>(1, total, st, d_gray, d_stego, g, qp, nullptr, 0, 0, 0)
+                       : launch_embed<svs::QM_F32, 1>(1, total, st, d_gray, d_stego, g, qp, nullptr, 0, 0, 0);
+        }
         g.xcd_chunk = env_chunk("SVS_EMBED_XCD_CHUNK", kEighth);
         if (use == 0) {
-            if (n_bits == 0) {   // empty payload: the reference's loops break before the first block
-                if (d_gray == d_stego) return SVS_OK;
-                g.n_ac = 1;
-                return launch_embed<svs::QM_F32, 1>(1, total, st, d_gray, d_stego, g, qp, nullptr, 0, 0, 0, nullptr);
-            }
-            // delta <= 0 or no coefficients: nothing is consumed, so every block is entered and round-tripped
+            // a non-empty payload of which nothing can be embedded (delta <= 0, no coefficients): the reference still
+            // enters and round-trips every block (config_and_setup.py:143-145,166-169); only the exact arithmetic
+            // reproduces what that does to the pixels, so every mode takes that kernel here
             g.n_ac = 0;
             return launch_embed_exact(svs::QM_F32, total, st, d_gray, d_stego, g, qp, nullptr, 0, 1, 0, exact_pair);
         }
@@ -571,45 +479,26 @@ int svs_embed_dev(const uint8_t *d_gray, uint8_t *d_stego, const svs_planes *pla
         if (n_embedded) *n_embedded = use;
         return SVS_OK;
     }
-    if (use == 0) {
-        if (n_bits > 0) {
-            // a non-empty payload of which nothing can be embedded (delta <= 0, no coefficients): the reference still
-            // enters and round-trips every block (config_and_setup.py:143-145,166-169); only the exact arithmetic
-            // reproduces what that does to the pixels, so FAST takes that kernel here
-            g.xcd_chunk = env_chunk("SVS_EMBED_XCD_CHUNK", kEighth);
-            g.n_ac = 0;
-            return launch_embed_exact(svs::QM_F32, total, st, d_gray, d_stego, g, qp, nullptr, 0, 1, 0, exact_pair);
-        }
-        // empty payload: pure copy, every block is "past the budget"
-        if (d_gray == d_stego) return SVS_OK;
-        g.n_ac = 1;
-        return two ? launch_embed<svs::QM_F32, 2>(1, total, st, d_gray, d_stego, g, qp, nullptr, 0, 0, 0, nullptr)
-                   : launch_embed<svs::QM_F32, 1>(1, total, st, d_gray, d_stego, g, qp, nullptr, 0, 0, 0, nullptr);
-    }
     const uint64_t last_byte = (bit_offset + use + 7) / 8;
     const uint64_t words = (last_byte + 3) / 4;
     if (words >= (1ull << 32)) return fail(SVS_ERR_INVALID_ARG, "payload too large for one call");
     const uint32_t *bw = reinterpret_cast<const uint32_t *>(d_bits_packed);
-    const int rows = rows_for(n);
-    // replay map: which blocks the fast kernel leaves to the exact arithmetic (svs_device.hpp "REPLAY MAP")
-    const int bpl = two ? 2 : 1;
-    const uint64_t map_words = replay_map_words(total, bpl);
-    uint64_t *d_map = nullptr;
-    if (int rc = replay_map_for(st, map_words, &d_map)) return rc;
+    if (rows == 1) {
+        svs::make_guard(delta, 1, &qp);
+        if (const char *sc = getenv("SVS_GUARD_SCALE")) {   // experiment knob: NOT bit-identical any more when < 1
+            const float f = (float)atof(sc);
+            qp.g_sum *= f; qp.g_resid *= f; qp.g_delta *= f;
+        }
+    }
     int rc;
-#define SVS_GO(QM)                                                                                                          \
-    rc = two ? launch_embed<QM, 2>(rows, total, st, d_gray, d_stego, g, qp, bw, bit_offset, use, (uint32_t)words, d_map)   \
-             : launch_embed<QM, 1>(rows, total, st, d_gray, d_stego, g, qp, bw, bit_offset, use, (uint32_t)words, d_map)
+#define SVS_GO(QM)                                                                                                   \
+    rc = two ? launch_embed<QM, 2>(rows, total, st, d_gray, d_stego, g, qp, bw, bit_offset, use, (uint32_t)words)    \
+             : launch_embed<QM, 1>(rows, total, st, d_gray, d_stego, g, qp, bw, bit_offset, use, (uint32_t)words)
     if (qm == svs::QM_DOUBLE) SVS_GO(svs::QM_DOUBLE);
     else if (qm == svs::QM_POW2) SVS_GO(svs::QM_POW2);
     else SVS_GO(svs::QM_F32);
 #undef SVS_GO
-    if (!rc)
-        rc = launch_embed_replay(qm, st, d_gray, d_stego, g, qp, bw, bit_offset, use, (uint32_t)words, d_map, map_words);
-    if (rc) {
-        replay_map_discard(st);
-        return rc;
-    }
+    if (rc) return rc;
     if (n_embedded) *n_embedded = use;
     return SVS_OK;
 }
@@ -818,7 +707,6 @@ int svs_embed_bgr_dev(const uint8_t *d_bgr_in, int64_t in_row_pitch, int64_t in_
     if (n_embedded) *n_embedded = 0;
     if (total == 0) return SVS_OK;
     if (flags & ~(SVS_EXACT_POCKETFFT | SVS_EXACT_GUARDED)) return fail(SVS_ERR_INVALID_ARG, "unknown flags 0x%x", flags);
-    if (flags & SVS_EXACT_GUARDED) flags = SVS_EXACT_POCKETFFT;   // the fused colour path has no guarded kernel (yet)
     if (d_gray_ref && ((uintptr_t)d_gray_ref % 8)) return fail(SVS_ERR_INVALID_ARG, "gray pointer must be 8-byte aligned");
     svs::ColourParams c;
     if (int rc = colour_params(planes, d_bgr_in, in_row_pitch, in_frame_pitch, d_bgr_out, out_row_pitch, out_frame_pitch,
@@ -831,19 +719,25 @@ int svs_embed_bgr_dev(const uint8_t *d_bgr_in, int64_t in_row_pitch, int64_t in_
     if (!(delta > 0.0) || n == 0) use = 0;
     if (use > 0 && (!d_bits_packed || ((uintptr_t)d_bits_packed % 4)))
         return fail(SVS_ERR_INVALID_ARG, "bits pointer NULL or not 4-byte aligned");
-    // nothing embeddable but a non-empty payload: every block is round-tripped, which only the exact arithmetic reproduces
-    const bool exact = (flags & SVS_EXACT_POCKETFFT) != 0 || (use == 0 && n_bits > 0);
+    // kernel family as in svs_embed_dev: the streaming arithmetic (with its in-kernel exact replay) for FAST and - with one
+    // coefficient row, where it is bit-identical - for GUARDED; the exact arithmetic otherwise, and whenever a non-empty
+    // payload cannot be embedded (every block is then round-tripped, which only the exact arithmetic reproduces)
+    const int rows_n = rows_for(n);
+    const bool in_range = delta >= SVS_GUARD_DELTA_MIN && delta <= SVS_GUARD_DELTA_MAX;
+    const bool streaming = use > 0 && in_range && !(flags & SVS_EXACT_POCKETFFT) && (rows_n == 1 || !(flags & SVS_EXACT_GUARDED));
+    const bool exact = !streaming && (use > 0 || n_bits > 0);
     svs::QimParams qp;
     const int qm = make_qim(use == 0 ? 1.0 : delta, &qp);
+    if (streaming && rows_n == 1) svs::make_guard(delta, 1, &qp);
     g.xcd_chunk = env_chunk("SVS_EMBED_XCD_CHUNK", kEighth);
     const hipStream_t st = (hipStream_t)stream;
     const uint32_t *bw = reinterpret_cast<const uint32_t *>(d_bits_packed);
     uint64_t kernel_bits = use;
     uint32_t words = 0;
     if (use == 0) {
-        // nothing to embed.  EXACT with a non-empty payload: every block is still round-tripped (n_ac = 0 in the kernel);
+        // nothing to embed.  With a non-empty payload every block is still round-tripped (n_ac = 0 in the exact kernel);
         // otherwise the frames are just converted BGR -> gray -> BGR
-        if (exact && n_bits > 0) { g.n_ac = 0; kernel_bits = 1; } else { g.n_ac = 1; kernel_bits = 0; }
+        if (exact) { g.n_ac = 0; kernel_bits = 1; } else { g.n_ac = 1; kernel_bits = 0; }
         bw = nullptr;
     } else {
         const uint64_t w64 = ((bit_offset + use + 7) / 8 + 3) / 4;
@@ -851,31 +745,17 @@ int svs_embed_bgr_dev(const uint8_t *d_bgr_in, int64_t in_row_pitch, int64_t in_
         words = (uint32_t)w64;
     }
     const int rows = rows_for((int)g.n_ac);
-    const bool replay = !exact && use > 0;   // FAST with something to embed: second pass over the replay map
-    const uint64_t map_words = replay_map_words(total, 1);
-    uint64_t *d_map = nullptr;
-    if (replay)
-        if (int rc = replay_map_for(st, map_words, &d_map)) return rc;
     int rc;
 #define SVS_GO(QM)                                                                                                       \
     rc = exact ? launch_embed_bgr<QM, true>(rows, total, st, d_bgr_in, d_bgr_out, d_gray_ref, g, c, qp, bw, bit_offset,   \
-                                            kernel_bits, words, nullptr)                                                  \
+                                            kernel_bits, words)                                                           \
                : launch_embed_bgr<QM, false>(rows, total, st, d_bgr_in, d_bgr_out, d_gray_ref, g, c, qp, bw, bit_offset,  \
-                                             kernel_bits, words, d_map);                                                  \
-    if (!rc && replay) {                                                                                                 \
-        hipLaunchKernelGGL((svs::embed_bgr_replay_kernel<QM>), dim3(svs::replay_grid(map_words)),                        \
-                           dim3(SVS_REPLAY_WG), 0, st, d_bgr_in, d_bgr_out, g, c, qp, bw, bit_offset, kernel_bits, words, d_map,  \
-                           (uint32_t)map_words);                                                                         \
-        if (hipGetLastError() != hipSuccess) rc = fail(SVS_ERR_HIP, "embed_bgr_replay_kernel launch failed");            \
-    }
+                                             kernel_bits, words);
     if (qm == svs::QM_DOUBLE) { SVS_GO(svs::QM_DOUBLE) }
     else if (qm == svs::QM_POW2) { SVS_GO(svs::QM_POW2) }
     else { SVS_GO(svs::QM_F32) }
 #undef SVS_GO
-    if (rc) {
-        if (replay) replay_map_discard(st);
-        return rc;
-    }
+    if (rc) return rc;
     if (n_embedded) *n_embedded = use;
     return SVS_OK;
 }

@@ -115,113 +115,6 @@ __device__ __forceinline__ void store_rows(uint8_t *dst, int64_t row_pitch, cons
 #endif
 }
 
-// ---------------------------------------------------------------------------------------
-// EMBED: one lane = BPL adjacent blocks.  grid = ceil(total_blocks / (SVS_WG*BPL)) workgroups of SVS_WG.
-// BPL = 2 needs an even number of blocks per row and 16-byte aligned rows (host checks).
-// HBM traffic per block: 64 B read + 64 B written + n payload bits read.
-// ---------------------------------------------------------------------------------------
-// bit i of x -> bit 2i (the even bits of a 64-bit word)
-__device__ __forceinline__ uint64_t spread_bits(uint32_t x32) {
-    uint64_t x = x32;
-    x = (x | (x << 16)) & 0x0000FFFF0000FFFFull;
-    x = (x | (x << 8)) & 0x00FF00FF00FF00FFull;
-    x = (x | (x << 4)) & 0x0F0F0F0F0F0F0F0Full;
-    x = (x | (x << 2)) & 0x3333333333333333ull;
-    x = (x | (x << 1)) & 0x5555555555555555ull;
-    return x;
-}
-
-#ifndef SVS_U2_MIN_WAVES
-#define SVS_U2_MIN_WAVES 6  // register target of the two-row embed kernel (80 VGPRs: +0.4..2.8 % over the default 87)
-#endif
-// `gray` and `stego` may be the same buffer (in-place embedding, include/svsdct.h), so neither is __restrict__: every
-// lane loads its own rows before it stores them and touches nobody else's.
-//
-// REPLAY MAP.  A block whose change is structurally zero (svs::embed_block returns true) must come out of the
-// pocketfft-identical arithmetic instead - 2 000 VALU operations and 140 VGPRs that this kernel cannot afford inline.
-// Such a block is left as it was (not stored) and flagged in the replay map, one bit per block: bit b of 64-bit word w
-// stands for global block 64 w + b.  A wave owns the word(s) of its 64 (128 with two blocks per lane) consecutive blocks
-// and stores them - from its ballot(s) - only when they are non-zero.  embed_replay_kernel then redoes exactly those blocks and clears the words it consumed,
-// so the map - a per-stream buffer owned by the library, zeroed when it is allocated - is all zeros again between calls.
-// On noise-like content nothing is ever flagged: this kernel does not touch the map and the second launch is one read of it.
-template <int U, int QM, int BPL, int NFIX = 0>
-__global__ __launch_bounds__(SVS_WG, (U == 2 ? SVS_U2_MIN_WAVES : 1)) void embed_kernel(const uint8_t *gray,
-                                                    uint8_t *stego, const Geometry g,
-                                                    const QimParams qp,
-                                                    const uint32_t *__restrict__ bits,
-                                                    const uint64_t bit_offset, const uint64_t n_bits,
-                                                    const uint32_t n_words, uint64_t *__restrict__ replay_map) {
-    const uint32_t tile = tile_id(g.xcd_chunk);
-    const uint32_t gblock = (tile * (uint32_t)SVS_WG + threadIdx.x) * BPL;
-    bool replay_a = false, replay_b = false;
-    if (gblock < g.total_blocks) {
-        const int64_t off = block_offset(gblock, g);
-        typename RowVec<BPL>::type v[8];
-        load_rows<BPL>(gray + off, g.row_pitch, v);
-
-        const uint32_t n = g.n_ac;
-        const uint64_t first = (uint64_t)gblock * n;  // stream index of this lane's first bit
-        if (first >= n_bits) {
-            // past the budget: byte-identical copy (the reference's loops `break`, :130,:132)
-            if (stego != gray) store_rows<BPL>(stego + off, g.row_pitch, v);
-        } else {
-            uint32_t ax[8], ay[8];
-#pragma unroll
-            for (int r = 0; r < 8; ++r) { ax[r] = v[r].x; ay[r] = v[r].y; }
-            {
-                uint32_t hi, lo;
-                payload_window(bits, n_words, bit_offset + first, hi, lo);
-                replay_a = embed_block<U, QM, NFIX>(ax, ay, n, block_budget(first, n_bits, n), hi, lo, qp);
-            }
-#pragma unroll
-            for (int r = 0; r < 8; ++r) { v[r].x = ax[r]; v[r].y = ay[r]; }
-            if constexpr (BPL == 2) {
-                uint32_t bx[8], by[8];
-#pragma unroll
-                for (int r = 0; r < 8; ++r) { bx[r] = v[r].z; by[r] = v[r].w; }
-                // a budget of 0 (only the lane the payload ends in can see it here) yields an all-zero
-                // change, i.e. block B is stored back unchanged - no branch needed
-                uint32_t hi, lo;
-                payload_window(bits, n_words, bit_offset + first + n, hi, lo);
-                replay_b = embed_block<U, QM, NFIX>(bx, by, n, block_budget(first + n, n_bits, n), hi, lo, qp);
-#pragma unroll
-                for (int r = 0; r < 8; ++r) { v[r].z = bx[r]; v[r].w = by[r]; }
-            }
-            if (!(replay_a | replay_b)) {
-                store_rows<BPL>(stego + off, g.row_pitch, v);
-            } else if constexpr (BPL == 2) {  // rare: store only the block that keeps its fast result
-                typename RowVec<1>::type h[8];
-                if (!replay_a) {
-#pragma unroll
-                    for (int r = 0; r < 8; ++r) { h[r].x = v[r].x; h[r].y = v[r].y; }
-                    store_rows<1>(stego + off, g.row_pitch, h);
-                }
-                if (!replay_b) {
-#pragma unroll
-                    for (int r = 0; r < 8; ++r) { h[r].x = v[r].z; h[r].y = v[r].w; }
-                    store_rows<1>(stego + off + 8, g.row_pitch, h);
-                }
-            }
-        }
-    }
-    // publication: the wave owns its map word(s), so one lane stores the ballot - and only when it is non-zero (rare;
-    // replay_map is non-null whenever a block can be entered)
-    const uint64_t ma = __ballot(replay_a);
-    const uint64_t mb = BPL == 2 ? __ballot(replay_b) : 0ull;
-    if ((ma | mb) != 0 && (threadIdx.x & 63u) == 0) {
-        uint64_t *slot = replay_map + ((uint64_t)tile * (SVS_WG / 64) + (threadIdx.x >> 6)) * BPL;
-        if constexpr (BPL == 2) {  // lane l owns blocks 2l and 2l+1 of the wave's 128: interleave the two ballots
-            slot[0] = spread_bits((uint32_t)ma) | (spread_bits((uint32_t)mb) << 1);
-            slot[1] = spread_bits((uint32_t)(ma >> 32)) | (spread_bits((uint32_t)(mb >> 32)) << 1);
-        } else {
-            slot[0] = ma;
-        }
-    }
-}
-
-// global block a bit of the replay map stands for: bit b of word w = block 64 w + b, whatever BPL the first pass ran with
-__device__ __forceinline__ uint32_t replay_block(uint32_t word, uint32_t bit) { return 64u * word + bit; }
-
 // Tail of the extract kernels: a wavefront's 64*BPL consecutive blocks produce exactly n*BPL aligned
 // 64-bit words of the packed stream.  The wave assembles them in a private LDS array of big-endian dwords
 // (stream bit p of the wave's chunk = bit 31 - p%32 of dword p/32): every lane ORs its n-bit string in at bit
@@ -494,105 +387,27 @@ __global__ __launch_bounds__(SVS_WG, SVS_EXACT2_MIN_WAVES) void embed_exact_pair
     }
 }
 
-// Second pass of FAST embedding: the blocks embed_kernel marked in the replay map are redone with the exact arithmetic,
-// read from `gray` (embed_kernel left them untouched, also when embedding in place) and written to `stego`.
-// A wave reads SVS_REPLAY_WORDS map words (one per lane) and leaves if all are zero - with an all-zero map the whole pass is
-// a read of total_blocks / 8 bytes.  Otherwise it takes its non-zero words one at a time, the word broadcast to all lanes and lane i
-// redoing the block of bit i: the same lane-per-block mapping, coalescing and balance as embed_exact_kernel, so that
-// content full of flat areas (letterbox bars flag every block they cover) runs at that kernel's speed.  Consumed words
-// are cleared: the map is all zeros again when the pass has finished.
-// A wave takes SVS_REPLAY_WORDS map words (lanes 0 .. SVS_REPLAY_WORDS-1 fetch one each): fewer words per wave means more
-// waves to share a flat area's blocks (64 words = 4 096 blocks would leave a letterbox bar to a handful of waves running
-// one at a time per SIMD) at the price of more waves to launch when the map is empty.
-#ifndef SVS_REPLAY_WORDS
-#define SVS_REPLAY_WORDS 32
-#endif
-#ifndef SVS_REPLAY_WG
-#define SVS_REPLAY_WG 256  // threads per workgroup of the replay kernels: with an empty map the pass costs its workgroup count
-#endif
-struct ReplayWork {
-    uint64_t mine;     // this lane's map word
-    uint64_t pending;  // ballot: lanes of the wave whose word is non-zero
-    uint32_t first;    // index of the wave's first map word
-};
-__device__ __forceinline__ ReplayWork replay_fetch(uint64_t *__restrict__ replay_map, uint32_t map_words) {
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wave = blockIdx.x * (uint32_t)(SVS_REPLAY_WG / 64) + (threadIdx.x >> 6);
-    ReplayWork w;
-    w.first = wave * (uint32_t)SVS_REPLAY_WORDS;
-    const uint32_t word = w.first + lane;
-    const bool mine = lane < (uint32_t)SVS_REPLAY_WORDS && word < map_words;
-    w.mine = mine ? replay_map[word] : 0ull;
-    w.pending = __ballot(w.mine != 0);
-    if (w.mine != 0) replay_map[word] = 0;
-    return w;
-}
-// workgroups a replay launch needs for `map_words` words
-__host__ __device__ inline uint32_t replay_grid(uint64_t map_words) {
-    const uint64_t per_wg = (uint64_t)(SVS_REPLAY_WG / 64) * SVS_REPLAY_WORDS;
-    return (uint32_t)((map_words + per_wg - 1) / per_wg);
-}
-__device__ __forceinline__ uint64_t replay_broadcast(uint64_t v, uint32_t src_lane) {  // src_lane: wave-uniform
-    const uint32_t lo = __builtin_amdgcn_readlane((int)(uint32_t)v, (int)src_lane);
-    const uint32_t hi = __builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), (int)src_lane);
-    return ((uint64_t)hi << 32) | lo;
-}
-
-template <int QM>
-__global__ __launch_bounds__(SVS_REPLAY_WG, SVS_EXACT_MIN_WAVES) void embed_replay_kernel(const uint8_t *gray, uint8_t *stego,
-                                                          const Geometry g, const QimParams qp,
-                                                          const uint32_t *__restrict__ bits, const uint64_t bit_offset,
-                                                          const uint64_t n_bits, const uint32_t n_words,
-                                                          uint64_t *__restrict__ replay_map,
-                                                          const uint32_t map_words) {
-    const uint32_t lane = threadIdx.x & 63u;
-    ReplayWork work = replay_fetch(replay_map, map_words);
-    const uint32_t n = g.n_ac;
-    while (work.pending != 0) {  // wave-uniform
-        const uint32_t src = (uint32_t)__builtin_ctzll(work.pending);
-        work.pending &= work.pending - 1;
-        const uint64_t todo = replay_broadcast(work.mine, src);
-        if (!((todo >> lane) & 1ull)) continue;
-        const uint32_t gblock = replay_block(work.first + src, lane);
-        const int64_t off = block_offset(gblock, g);
-        typename RowVec<1>::type v[8];
-        load_rows<1>(gray + off, g.row_pitch, v);
-        uint32_t ax[8], ay[8];
-#pragma unroll
-        for (int r = 0; r < 8; ++r) { ax[r] = v[r].x; ay[r] = v[r].y; }
-        const uint64_t first = (uint64_t)gblock * n;
-        uint32_t hi, lo;
-        payload_window(bits, n_words, bit_offset + first, hi, lo);
-        // letterbox bars and the like: when every block of this pass is constant, the forward transform is two lines
-        uint32_t differs = 0;
-        const uint32_t splat = (ax[0] & 0xffu) * 0x01010101u;
-#pragma unroll
-        for (int r = 0; r < 8; ++r) differs |= (ax[r] ^ splat) | (ay[r] ^ splat);
-        const bool all_constant = __ballot(differs != 0) == 0;   // over the lanes active in this pass
-        embed_block_exact<8, QM>(ax, ay, n, block_budget(first, n_bits, n), hi, lo, qp, all_constant);
-#pragma unroll
-        for (int r = 0; r < 8; ++r) { v[r].x = ax[r]; v[r].y = ay[r]; }
-        store_rows<1>(stego + off, g.row_pitch, v);
-    }
-}
-
 // ---------------------------------------------------------------------------------------
-// GUARDED embed (include/svsdct.h SVS_EXACT_GUARDED, one coefficient row): the reference's pixels bit for bit, at the FAST
-// kernel's traffic and nearly its instruction count.
-//   phase 1  lane = block: svs::embed_block_guarded - pocketfft-identical payload coefficients, sparse inverse of the
-//            change, and the per-block error bound that decides whether floor(pixel + change) is certain to be the
-//            reference's truncation for all 64 pixels (a few % of the blocks are not: svs_block.hpp "GUARDED mode").
-//   phase 2  the workgroup's undecided blocks are compacted into an LDS worklist (one LDS atomic per wave) and redone
-//            with the pocketfft-identical arithmetic by EIGHT LANES PER BLOCK: lane r of a group transforms column r,
-//            then row r, of its block - the four 1-D passes of the reference (vertical / horizontal forward, vertical /
-//            horizontal inverse, config_and_setup.py:135,168) with a transposition through a wave-private LDS tile in
-//            between.  Every value is produced by the same svs::pf operation sequence as in embed_block_exact, so the
-//            bits are the same; what changes is the shape: about 40 VGPRs and 430 instructions per pass of 8 blocks
-//            instead of 140 VGPRs and 2 100 per pass of 64 - affordable inside the streaming kernel, and dense when only
-//            a handful of the workgroup's 256 blocks need it.
-//   phase 3  every lane stores its block (its own result or the one it collects from the worklist): the wave's stores
-//            cover whole 512-byte row segments exactly as in the FAST kernel - no partial lines, no second launch, no
-//            extra HBM traffic.
+// EMBED (FAST and GUARDED modes, include/svsdct.h): one lane = BPL adjacent blocks, grid = ceil(total_blocks / (SVS_WG*BPL))
+// workgroups of SVS_WG.  BPL = 2 (16-byte row accesses) needs an even number of blocks per row and 16-byte aligned rows
+// (the host checks) and is instantiated for one coefficient row only.
+// HBM traffic per block: 64 B read + 64 B written + n payload bits read - nothing else, whatever the content.
+//   phase 1  lane = block: the cheap arithmetic (svs_block.hpp) - U = 1: embed_block_guarded (pocketfft-identical payload
+//            coefficients, sparse inverse, rigorous per-block error bound: the result is the reference's, bit for bit);
+//            U >= 2: embed_block (FMA-factored transform, per-pixel guard of SVS_FAST_GUARD).  Either returns "undecided"
+//            for the few blocks whose truncation the reference's own float32 noise decides.
+//   phase 2  the wave's undecided blocks are compacted into a wave-private LDS worklist (ballot + mbcnt: no atomics, no
+//            barrier) and redone with the pocketfft-identical arithmetic by EIGHT LANES PER BLOCK: lane r of a group
+//            transforms column r, then row r, of its block - the four 1-D passes of the reference (vertical / horizontal
+//            forward, vertical / horizontal inverse, config_and_setup.py:135,168) with a transposition through a
+//            wave-private LDS tile in between.  Every value comes from the same svs::pf operation sequence as in
+//            embed_block_exact, so the bits are the same; what changes is the shape: about 40 VGPRs and 300-450
+//            instructions per pass of 8 blocks instead of 140 VGPRs and 2 100 per pass of 64 - affordable inside the
+//            streaming kernel.  More than SVS_GUARD_CAP undecided blocks in a wave (flat content) take further rounds.
+//   phase 3  every lane stores its rows (its own result, or the one it collected from the worklist): the wave's stores
+//            cover whole 512-byte row segments - no partial lines, no second launch, no scratch buffer in HBM.
+// `gray` and `stego` may be the same buffer (in-place embedding, include/svsdct.h), so neither is __restrict__: every
+// lane loads its own rows before it stores them and touches nobody else's.
 // ---------------------------------------------------------------------------------------
 struct GuardEntry {
     uint32_t px[16];   // rows as (low dword, high dword) pairs: the original pixels in, the exact stego pixels out
@@ -602,6 +417,9 @@ struct GuardEntry {
 };
 #define SVS_GUARD_TILE 72   // floats per block of the transposition tile: element (i, j) at 9 i + j; 72 = 8 (mod 64) keeps the
                             // eight groups of a wave on different LDS banks in both directions
+#ifndef SVS_GUARD_CAP
+#define SVS_GUARD_CAP 32    // worklist entries per wave and round (80 B each)
+#endif
 
 template <int QM>
 __device__ __forceinline__ void guard_replay8(GuardEntry *e, float *t, uint32_t r, uint32_t n, const QimParams &qp) {
@@ -620,31 +438,32 @@ __device__ __forceinline__ void guard_replay8(GuardEntry *e, float *t, uint32_t 
     for (int x = 0; x < 8; ++x) a[x] = t[9 * r + x];   // V[r][x]
     wave_lds_fence();
     pf::dct2_8(a, b);                       // b[v] = D[r][v]: coefficient row r
-    // QIM on flat indices k = 8 r + v in 1..n (config_and_setup.py:139-158)
+    // to coefficient COLUMNS (what the vertical inverse wants): lane r takes D[u][r], u = 0..7
+#pragma unroll
+    for (int v = 0; v < 8; ++v) t[9 * r + v] = b[v];
+    wave_lds_fence();
+#pragma unroll
+    for (int u = 0; u < 8; ++u) a[u] = t[9 * u + r];
+    wave_lds_fence();
+    // QIM on flat indices k = 8 u + r in 1..n (config_and_setup.py:139-158): one coefficient per lane and row, so a wave
+    // runs n / 8 + 1 quantiser sequences, each on all the lanes that have a coefficient
     const uint32_t hi = e->hi, lo = e->lo, nb = e->nb;
 #pragma unroll
-    for (int v = 0; v < 8; ++v) {
-        const uint32_t k = 8u * r + v;
+    for (int u = 0; u < 8; ++u) {
+        const uint32_t k = 8u * u + r;
         if (k >= 1u && k <= n) {
             const int i = (int)k - 1;
             const int bit = (int)window_bit(hi, lo, i);
-            const float c = b[v];
+            const float c = a[u];
             int q = quant_index<QM>(c, qp);
             q += bit - (q & 1);
             float cn;
             if constexpr (QM == QM_DOUBLE) cn = (float)((double)q * qp.delta_d);
             else cn = (float)q * qp.delta_f;
-            b[v] = ((uint32_t)i < nb) ? cn : c;
+            a[u] = ((uint32_t)i < nb) ? cn : c;
         }
     }
-    // vertical inverse first (axis 0, :168): lane r takes coefficient column r
-#pragma unroll
-    for (int v = 0; v < 8; ++v) t[9 * r + v] = b[v];
-    wave_lds_fence();
-#pragma unroll
-    for (int u = 0; u < 8; ++u) a[u] = t[9 * u + r];   // D'[u][r]
-    wave_lds_fence();
-    pf::dct3_8(a, b);                       // b[y] = P[y][r]
+    pf::dct3_8(a, b);                       // vertical inverse first (axis 0, :168): b[y] = P[y][r]
 #pragma unroll
     for (int y = 0; y < 8; ++y) t[9 * y + r] = b[y];
     wave_lds_fence();
@@ -657,75 +476,134 @@ __device__ __forceinline__ void guard_replay8(GuardEntry *e, float *t, uint32_t 
     e->px[2 * r + 1] = hi4;
 }
 
-template <int QM>
-__global__ __launch_bounds__(SVS_WG) void embed_guarded_kernel(const uint8_t *gray,   // may alias stego
-                                                             uint8_t *stego, const Geometry g, const QimParams qp,
-                                                             const uint32_t *__restrict__ bits, const uint64_t bit_offset,
-                                                             const uint64_t n_bits, const uint32_t n_words,
-                                                             unsigned long long *__restrict__ replay_counter) {
-    __shared__ GuardEntry entries[SVS_WG];
+// phase 1 for one block whose rows are ax/ay, in place: stego pixels out - unless the block is undecided, then its original
+// pixels are left untouched (svs_block.hpp decides before it writes).  -> undecided
+template <int U, int QM, int NFIX>
+__device__ __forceinline__ bool guard_phase1(uint32_t (&ax)[8], uint32_t (&ay)[8], uint32_t n, uint64_t first,
+                                             const QimParams &qp, const uint32_t *__restrict__ bits,
+                                             uint64_t bit_offset, uint64_t n_bits, uint32_t n_words) {
+    uint32_t hi, lo;
+    payload_window(bits, n_words, bit_offset + first, hi, lo);
+    const uint32_t nb = block_budget(first, n_bits, n);
+    if constexpr (U == 1) return embed_block_guarded<QM>(ax, ay, n, nb, hi, lo, qp);
+    else return embed_block<U, QM, NFIX>(ax, ay, n, nb, hi, lo, qp);
+}
+
+// what phase 2 needs to rebuild a block's payload window (kept out of the lanes' registers on the common path)
+struct GuardPayload {
+    const uint32_t *bits;
+    uint64_t bit_offset, n_bits;
+    uint32_t n_words;
+};
+
+// phase 2: the wave's undecided blocks (a: first block of every lane, b: second block when two blocks per lane; their rows
+// still hold the ORIGINAL pixels, first_a / first_b are their first stream bits) through the worklist `entries` (CAP entries)
+// and the transposition tile `tile` (8 * SVS_GUARD_TILE floats), both private to the wave.  On return the rows of undecided
+// blocks hold the exact stego pixels.  Returns the number of blocks redone.
+template <int QM, bool TWO, int CAP = SVS_GUARD_CAP>
+__device__ __forceinline__ uint32_t guard_phase2(GuardEntry *entries, float *tile, uint32_t lane, uint32_t n,
+                                                 const QimParams &qp, const GuardPayload &pl,
+                                                 bool und_a, uint64_t first_a, uint32_t (&ax)[8], uint32_t (&ay)[8],
+                                                 bool und_b, uint64_t first_b, uint32_t (&bx)[8], uint32_t (&by)[8]) {
+    const uint64_t mask_a = __ballot(und_a);
+    const uint64_t mask_b = TWO ? __ballot(und_b) : 0ull;
+    if ((mask_a | mask_b) == 0) return 0;   // wave-uniform: the common case costs two ballots
+    const uint32_t n_a = (uint32_t)__popcll(mask_a), total = n_a + (uint32_t)__popcll(mask_b);
+    const uint32_t rank_a = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask_a >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask_a, 0u));
+    const uint32_t rank_b = n_a + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask_b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask_b, 0u));
+    for (uint32_t base = 0; base < total; base += (uint32_t)CAP) {   // wave-uniform
+        const bool mine_a = und_a && rank_a >= base && rank_a < base + (uint32_t)CAP;
+        const bool mine_b = TWO && und_b && rank_b >= base && rank_b < base + (uint32_t)CAP;
+        if (mine_a) {
+            GuardEntry *e = &entries[rank_a - base];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) { e->px[2 * r] = ax[r]; e->px[2 * r + 1] = ay[r]; }
+            uint32_t hi, lo;
+            payload_window(pl.bits, pl.n_words, pl.bit_offset + first_a, hi, lo);
+            e->hi = hi; e->lo = lo; e->nb = block_budget(first_a, pl.n_bits, n);
+        }
+        if (mine_b) {
+            GuardEntry *e = &entries[rank_b - base];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) { e->px[2 * r] = bx[r]; e->px[2 * r + 1] = by[r]; }
+            uint32_t hi, lo;
+            payload_window(pl.bits, pl.n_words, pl.bit_offset + first_b, hi, lo);
+            e->hi = hi; e->lo = lo; e->nb = block_budget(first_b, pl.n_bits, n);
+        }
+        wave_lds_fence();
+        const uint32_t todo = min(total - base, (uint32_t)CAP);
+        for (uint32_t first = 0; first < todo; first += 8u) {
+            const uint32_t idx = first + (lane >> 3);
+            if (idx < todo) guard_replay8<QM>(&entries[idx], tile + (lane >> 3) * SVS_GUARD_TILE, lane & 7u, n, qp);
+        }
+        wave_lds_fence();
+        if (mine_a) {
+            const GuardEntry *e = &entries[rank_a - base];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) { ax[r] = e->px[2 * r]; ay[r] = e->px[2 * r + 1]; }
+        }
+        if (mine_b) {
+            const GuardEntry *e = &entries[rank_b - base];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) { bx[r] = e->px[2 * r]; by[r] = e->px[2 * r + 1]; }
+        }
+        wave_lds_fence();   // the next round overwrites the entries
+    }
+    return total;
+}
+
+#ifndef SVS_U1_MIN_WAVES
+#define SVS_U1_MIN_WAVES 1  // register target of the one-row, two-blocks-per-lane embed kernel (100 VGPRs: 4 waves per SIMD; forcing 5 spills 48 B into the hot path: 2.45 vs 1.65 ms)
+#endif
+#ifndef SVS_U2_MIN_WAVES
+#define SVS_U2_MIN_WAVES 5  // register target of the two-row embed kernel (92 VGPRs, no scratch; 6 spills 20-52 B)
+#endif
+template <int U, int QM, int BPL, int NFIX = 0>
+__global__ __launch_bounds__(SVS_WG, (U == 2 ? SVS_U2_MIN_WAVES : (U == 1 && BPL == 2 ? SVS_U1_MIN_WAVES : 1))) void embed_kernel(const uint8_t *gray,
+                                                    uint8_t *stego, const Geometry g, const QimParams qp,
+                                                    const uint32_t *__restrict__ bits, const uint64_t bit_offset,
+                                                    const uint64_t n_bits, const uint32_t n_words,
+                                                    unsigned long long *__restrict__ replay_counter) {
+    __shared__ GuardEntry entries[SVS_WG / 64][SVS_GUARD_CAP];
     __shared__ float tiles[SVS_WG / 64][8 * SVS_GUARD_TILE];
-    __shared__ uint32_t count;
-    if (threadIdx.x == 0) count = 0;
-    __syncthreads();
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    const uint32_t gblock = tile_id(g.xcd_chunk) * (uint32_t)SVS_WG + threadIdx.x;
+    const uint32_t gblock = (tile_id(g.xcd_chunk) * (uint32_t)SVS_WG + threadIdx.x) * BPL;
     const uint32_t n = g.n_ac;
-    const bool live = gblock < g.total_blocks;
-    bool undecided = false, write = false;
-    typename RowVec<1>::type v[8];
+    bool und_a = false, und_b = false, write = false;
+    typename RowVec<BPL>::type v[8];
+    uint32_t ax[8], ay[8], bx[8], by[8];
     int64_t off = 0;
-    uint32_t hi = 0, lo = 0, nb = 0;
-    if (live) {
+    if (gblock < g.total_blocks) {
         off = block_offset(gblock, g);
-        load_rows<1>(gray + off, g.row_pitch, v);
-        const uint64_t first = (uint64_t)gblock * n;
-        write = stego != gray;           // past the budget: byte-identical copy (:130,:132)
+        load_rows<BPL>(gray + off, g.row_pitch, v);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            ax[r] = v[r].x; ay[r] = v[r].y;
+            if constexpr (BPL == 2) { bx[r] = v[r].z; by[r] = v[r].w; }
+        }
+        const uint64_t first = (uint64_t)gblock * n;  // stream index of this lane's first bit
+        write = stego != gray;                         // past the budget: byte-identical copy (the reference's loops `break`, :130,:132)
         if (first < n_bits) {
             write = true;
-            uint32_t ax[8], ay[8];
-#pragma unroll
-            for (int r = 0; r < 8; ++r) { ax[r] = v[r].x; ay[r] = v[r].y; }
-            payload_window(bits, n_words, bit_offset + first, hi, lo);
-            nb = block_budget(first, n_bits, n);
-            undecided = embed_block_guarded<QM>(ax, ay, n, nb, hi, lo, qp);
-            if (!undecided) {
-#pragma unroll
-                for (int r = 0; r < 8; ++r) { v[r].x = ax[r]; v[r].y = ay[r]; }
+            und_a = guard_phase1<U, QM, NFIX>(ax, ay, n, first, qp, bits, bit_offset, n_bits, n_words);
+            if constexpr (BPL == 2) {   // a budget of 0 (only the lane the payload ends in can see it) leaves block B as it is
+                if (first + n < n_bits) und_b = guard_phase1<U, QM, NFIX>(bx, by, n, first + n, qp, bits, bit_offset, n_bits, n_words);
             }
         }
     }
-    // worklist slots: one LDS atomic per wave that has undecided blocks
-    const uint64_t mask = __ballot(undecided);
-    uint32_t slot = 0;
-    if (mask != 0) {
-        uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(&count, (uint32_t)__popcll(mask));
-        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-        slot = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-        if (undecided) {
-            GuardEntry *e = &entries[slot];
+    const GuardPayload pl{bits, bit_offset, n_bits, n_words};
+    const uint64_t first_a = (uint64_t)gblock * n;
+    const uint32_t redone = guard_phase2<QM, BPL == 2>(&entries[wave][0], &tiles[wave][0], lane, n, qp, pl, und_a, first_a, ax, ay,
+                                                       und_b, first_a + n, bx, by);
+    if (replay_counter != nullptr && redone != 0 && lane == 0) atomicAdd(replay_counter, (unsigned long long)redone);
+    if (write) {
 #pragma unroll
-            for (int r = 0; r < 8; ++r) { e->px[2 * r] = v[r].x; e->px[2 * r + 1] = v[r].y; }
-            e->hi = hi; e->lo = lo; e->nb = nb;
+        for (int r = 0; r < 8; ++r) {
+            v[r].x = ax[r]; v[r].y = ay[r];
+            if constexpr (BPL == 2) { v[r].z = bx[r]; v[r].w = by[r]; }
         }
+        store_rows<BPL>(stego + off, g.row_pitch, v);
     }
-    __syncthreads();
-    const uint32_t todo = count;   // workgroup-uniform
-    if (todo != 0) {
-        for (uint32_t first = wave * 8u; first < todo; first += 8u * (SVS_WG / 64)) {
-            const uint32_t idx = first + (lane >> 3);
-            if (idx < todo) guard_replay8<QM>(&entries[idx], &tiles[wave][(lane >> 3) * SVS_GUARD_TILE], lane & 7u, n, qp);
-        }
-        __syncthreads();
-        if (undecided) {
-            const GuardEntry *e = &entries[slot];
-#pragma unroll
-            for (int r = 0; r < 8; ++r) { v[r].x = e->px[2 * r]; v[r].y = e->px[2 * r + 1]; }
-        }
-        if (replay_counter != nullptr && threadIdx.x == 0) atomicAdd(replay_counter, (unsigned long long)todo);
-    }
-    if (write) store_rows<1>(stego + off, g.row_pitch, v);
 }
 
 template <int U, int QM>
@@ -997,11 +875,10 @@ __device__ __forceinline__ void wave_load_gray_halves(const uint8_t *bgr, const 
 
 // Gray rows of a wave's 64 blocks -> interleaved BGR with B = G = R, through the wave-private tile `mine` (8 rows x 64
 // lanes of 8 gray bytes): every store instruction covers 512 contiguous bytes.
-// `skip`: wave mask of blocks (bit = lane) whose output is NOT written (left to the replay pass)
 __device__ __forceinline__ void wave_store_gray_as_bgr(u32x2 *mine, uint32_t lane, uint32_t gblock, bool live,
                                                        const uint32_t (&ax)[8], const uint32_t (&ay)[8],
                                                        uint8_t *bgr_out, const Geometry &g,
-                                                       const ColourParams &c, uint64_t skip = 0) {
+                                                       const ColourParams &c) {
     if (live) {
 #pragma unroll
         for (int r = 0; r < 8; ++r) { u32x2 v; v.x = ax[r]; v.y = ay[r]; mine[r * 64 + lane] = v; }
@@ -1012,7 +889,7 @@ __device__ __forceinline__ void wave_store_gray_as_bgr(u32x2 *mine, uint32_t lan
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
         const uint32_t owner = wu.owner[j], part = wu.part[j];
-        if (!wu.live[j] || ((skip >> owner) & 1ull)) continue;
+        if (!wu.live[j]) continue;
         // gray pixels feeding the unit's two dwords (v_perm_b32: selector bytes 0-3 pick from the low gray dword,
         // 4-7 from the high one): part 0 = p0 p0 p0 p1 | p1 p1 p2 p2, part 1 = p2 p3 p3 p3 | p4 p4 p4 p5,
         // part 2 = p5 p5 p6 p6 | p6 p7 p7 p7
@@ -1072,31 +949,20 @@ __global__ __launch_bounds__(SVS_WG) void embed_bgr_kernel(const uint8_t *bgr_in
                                                         uint8_t *bgr_out, uint8_t *__restrict__ gray_ref,
                                                         const Geometry g, const ColourParams c, const QimParams qp,
                                                         const uint32_t *__restrict__ bits, const uint64_t bit_offset,
-                                                        const uint64_t n_bits, const uint32_t n_words,
-                                                        uint64_t *__restrict__ replay_map) {
-#if !defined(SVS_BGR_DIRECT_STORE)
+                                                        const uint64_t n_bits, const uint32_t n_words) {
+    // one wave-private 4 KB region per wave: row staging of the cooperative load, then (FAST) the worklist and transposition
+    // tile of the exact replay (svs::guard_phase2, 16 entries per round), then the stego tile of the cooperative store
     __shared__ __attribute__((aligned(16))) u32x2 lds_tile[SVS_WG / 64][8][64];
-#endif
+    static_assert(16 * sizeof(GuardEntry) + 8 * SVS_GUARD_TILE * sizeof(float) <= 8 * 64 * sizeof(u32x2), "wave region too small");
     const uint32_t tile = tile_id(g.xcd_chunk);
     const uint32_t gblock = tile * (uint32_t)SVS_WG + threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const bool live = gblock < g.total_blocks;
-    bool replay = false;  // FAST only: structurally zero change -> embed_bgr_replay_kernel redoes the block (see embed_kernel)
     uint32_t ax[8], ay[8];
-#if !defined(SVS_BGR_DIRECT_LOAD) && !defined(SVS_BGR_DIRECT_STORE)
     // cooperative load, four rows at a time: +5..7 % over per-lane loads at a 24-byte stride in FAST mode (62 -> 78 VGPRs),
     // neutral in EXACT mode; all eight rows at once cost 100+ VGPRs and gained 1 % (profiles/r01_aux_kernel_rates.txt)
-    wave_load_gray_halves(bgr_in, g, c, gblock - (threadIdx.x & 63u), threadIdx.x & 63u, &lds_tile[threadIdx.x >> 6][0][0], ax, ay);
-#else
-    if (live) {
-        const uint8_t *src = bgr_in + block_offset_bgr(gblock, g, c.in_row_pitch, c.in_frame_pitch);
-#pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            u32x2 q0, q1, q2;
-            load_bgr_row(src + r * c.in_row_pitch, q0, q1, q2);
-            bgr8_to_gray(q0, q1, q2, c, ax[r], ay[r]);
-        }
-    }
-#endif
+    wave_load_gray_halves(bgr_in, g, c, gblock - lane, lane, &lds_tile[wave][0][0], ax, ay);
+    bool und = false;
     if (live) {
         if (gray_ref != nullptr) {  // the operator's first return value: the gray frame before embedding
             uint8_t *ref = gray_ref + block_offset(gblock, g);
@@ -1109,71 +975,23 @@ __global__ __launch_bounds__(SVS_WG) void embed_bgr_kernel(const uint8_t *bgr_in
         const uint32_t n = g.n_ac;
         const uint64_t first = (uint64_t)gblock * n;
         if (first < n_bits) {
-            uint32_t hi, lo;
-            payload_window(bits, n_words, bit_offset + first, hi, lo);
-            if constexpr (EXACT) embed_block_exact<8, QM>(ax, ay, n, block_budget(first, n_bits, n), hi, lo, qp);
-            else replay = embed_block<U, QM>(ax, ay, n, block_budget(first, n_bits, n), hi, lo, qp);
+            if constexpr (EXACT) {
+                uint32_t hi, lo;
+                payload_window(bits, n_words, bit_offset + first, hi, lo);
+                embed_block_exact<8, QM>(ax, ay, n, block_budget(first, n_bits, n), hi, lo, qp);
+            } else {
+                und = guard_phase1<U, QM, 0>(ax, ay, n, first, qp, bits, bit_offset, n_bits, n_words);
+            }
         }
     }
-    const uint64_t skip = EXACT ? 0ull : __ballot(replay);   // the cooperative store below needs the wave's mask anyway
-    if constexpr (!EXACT) {
-        if (skip != 0 && (threadIdx.x & 63u) == 0)           // rare; one wave owns the word: a plain store will do
-            replay_map[(uint64_t)tile * (SVS_WG / 64) + (threadIdx.x >> 6)] = skip;
+    if constexpr (!EXACT) {   // undecided blocks: exact replay inside the wave (see embed_kernel)
+        GuardEntry *entries = reinterpret_cast<GuardEntry *>(&lds_tile[wave][0][0]);
+        float *t = reinterpret_cast<float *>(entries + 16);
+        const GuardPayload pl{bits, bit_offset, n_bits, n_words};
+        const uint64_t first = (uint64_t)gblock * g.n_ac;
+        guard_phase2<QM, false, 16>(entries, t, lane, g.n_ac, qp, pl, und, first, ax, ay, false, first, ax, ay);
     }
-#if defined(SVS_BGR_DIRECT_STORE)
-    if (live && !replay) {
-        uint8_t *dst = bgr_out + block_offset_bgr(gblock, g, c.out_row_pitch, c.out_frame_pitch);
-#pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            u32x2 q0, q1, q2;
-            gray8_to_bgr(ax[r], ay[r], q0, q1, q2);
-            store_bgr_row(dst + r * c.out_row_pitch, q0, q1, q2);
-        }
-    }
-#else
-    wave_store_gray_as_bgr(&lds_tile[threadIdx.x >> 6][0][0], threadIdx.x & 63u, gblock, live, ax, ay, bgr_out, g, c, skip);
-#endif
-}
-
-// Second pass of the FAST fused colour embed: blocks marked in the replay map are redone from the original BGR pixels
-// with the exact arithmetic (gray reference frame: already written by the first pass); work distribution as in
-// embed_replay_kernel.
-template <int QM>
-__global__ __launch_bounds__(SVS_REPLAY_WG, SVS_EXACT_MIN_WAVES) void embed_bgr_replay_kernel(const uint8_t *bgr_in, uint8_t *bgr_out,
-                                                          const Geometry g, const ColourParams c, const QimParams qp,
-                                                          const uint32_t *__restrict__ bits, const uint64_t bit_offset,
-                                                          const uint64_t n_bits, const uint32_t n_words,
-                                                          uint64_t *__restrict__ replay_map,
-                                                          const uint32_t map_words) {
-    const uint32_t lane = threadIdx.x & 63u;
-    ReplayWork work = replay_fetch(replay_map, map_words);
-    const uint32_t n = g.n_ac;
-    while (work.pending != 0) {  // wave-uniform; see embed_replay_kernel
-        const uint32_t src = (uint32_t)__builtin_ctzll(work.pending);
-        work.pending &= work.pending - 1;
-        const uint64_t todo = replay_broadcast(work.mine, src);
-        if (!((todo >> lane) & 1ull)) continue;
-        const uint32_t gblock = replay_block(work.first + src, lane);
-        const uint8_t *src_px = bgr_in + block_offset_bgr(gblock, g, c.in_row_pitch, c.in_frame_pitch);
-        uint32_t ax[8], ay[8];
-#pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            u32x2 q0, q1, q2;
-            load_bgr_row(src_px + r * c.in_row_pitch, q0, q1, q2);
-            bgr8_to_gray(q0, q1, q2, c, ax[r], ay[r]);
-        }
-        const uint64_t first = (uint64_t)gblock * n;
-        uint32_t hi, lo;
-        payload_window(bits, n_words, bit_offset + first, hi, lo);
-        embed_block_exact<8, QM>(ax, ay, n, block_budget(first, n_bits, n), hi, lo, qp);
-        uint8_t *dst = bgr_out + block_offset_bgr(gblock, g, c.out_row_pitch, c.out_frame_pitch);
-#pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            u32x2 q0, q1, q2;
-            gray8_to_bgr(ax[r], ay[r], q0, q1, q2);
-            store_bgr_row(dst + r * c.out_row_pitch, q0, q1, q2);
-        }
-    }
+    wave_store_gray_as_bgr(&lds_tile[wave][0][0], lane, gblock, live, ax, ay, bgr_out, g, c);
 }
 
 // extract straight from interleaved BGR frames (gray computed on the fly; pocketfft-identical forward)

@@ -23,12 +23,14 @@ from .native import Planes
 MAX_AC = 63
 
 # Transform mode (include/svsdct.h `flags`):
-#   "fast"   FMA-factored DCT on the coefficient rows the payload touches - contract parity (bits exact,
-#            PSNR within 0.01 dB), HBM-roofline speed.  Default of the device-pointer (throughput) level.
-#   "exact"  pocketfft-identical arithmetic on every block - stego pixels bit-identical to the reference.
-#   "guarded" the same bit-identical pixels from the guarded kernel (FAST-class speed: the cheap path wherever a rigorous
-#            error bound proves it equals the reference's truncation, the exact arithmetic for the few blocks where it
-#            cannot; n_ac <= 7) - falls back to "exact" kernels where it does not apply.
+#   "guarded" stego pixels bit-identical to the reference.  n_ac <= 7: the streaming kernel (cheap sparse transform wherever a
+#            rigorous bound on the reference's float32 round-trip noise proves it equals the reference's truncation, the
+#            pocketfft-identical arithmetic inside the same launch for the few blocks where it cannot); n_ac >= 8: the
+#            "exact" kernels.  Default of the NumPy level, the drop-in operator and the video pipelines.
+#   "fast"   n_ac <= 7: the same launch as "guarded".  n_ac >= 8: FMA-factored DCT on the coefficient rows the payload
+#            touches with a per-pixel guard - contract parity (bits exact, PSNR within 0.01 dB).  Default of the
+#            device-pointer (throughput) level.
+#   "exact"  pocketfft-identical arithmetic on every block, one lane per block - the yardstick (VALU-bound).
 # SVS_DCT_MODE=fast|exact|guarded overrides both defaults.
 _ENV_MODE = os.environ.get("SVS_DCT_MODE")
 
@@ -47,7 +49,7 @@ def mode_flags(mode, default: str) -> int:
 def host_level_mode() -> str:
     """transform mode of the NumPy-level entry points and of the drop-in pipelines built on them"""
     mode = _ENV_MODE or "exact"
-    mode_flags(mode, "exact")       # validates
+    mode_flags(mode, "guarded")       # validates
     return mode
 
 
@@ -129,7 +131,7 @@ def embed_frames(frames: np.ndarray, delta, n_ac, bits, bit_offset: int = 0, n_b
     done = C.c_uint64(0)
     planes = Planes.contiguous(f, h, w)
     rc = lib.svs_embed(stack.ctypes.data, stego.ctypes.data, C.byref(planes), float(delta), int(n_ac),
-                       packed.ctypes.data, int(bit_offset), int(n_bits), mode_flags(mode, "exact"), C.byref(done))
+                       packed.ctypes.data, int(bit_offset), int(n_bits), mode_flags(mode, "guarded"), C.byref(done))
     native.check(rc, "svs_embed")
     return stego, int(done.value)
 
@@ -146,7 +148,7 @@ def extract_frames(frames: np.ndarray, delta, n_ac, device: int = 0, mode: str |
     got = C.c_uint64(0)
     planes = Planes.contiguous(f, h, w)
     rc = lib.svs_extract(stack.ctypes.data, C.byref(planes), float(delta), int(n_ac), out.ctypes.data,
-                         out.size, mode_flags(mode, "exact"), C.byref(got))
+                         out.size, mode_flags(mode, "guarded"), C.byref(got))
     native.check(rc, "svs_extract")
     n = int(got.value)
     return out[: (n + 7) // 8], n
@@ -246,7 +248,7 @@ def embed_bgr_frames(frames_bgr: np.ndarray, delta, n_ac, bits, bit_offset: int 
     done = C.c_uint64(0)
     rc = lib.svs_embed_bgr(stack.ctypes.data, out.ctypes.data, gray.ctypes.data if want_gray else None,
                            C.byref(planes), wptr, float(delta), int(n_ac), packed.ctypes.data, int(bit_offset),
-                           int(n_bits), mode_flags(mode, "exact"), C.byref(done))
+                           int(n_bits), mode_flags(mode, "guarded"), C.byref(done))
     native.check(rc, "svs_embed_bgr")
     used = int(done.value)
     return out, gray, used

@@ -20,7 +20,7 @@ SVS_ERR_NO_DEVICE = -3
 SVS_ERR_CAPACITY = -4
 SVS_EXACT_POCKETFFT = 1      # flags bit: pocketfft-identical arithmetic (include/svsdct.h)
 SVS_EXACT_GUARDED = 2        # flags bit: the same bit-identical result through the guarded kernel where it applies
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class SvsNativeError(RuntimeError):

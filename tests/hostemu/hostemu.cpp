@@ -122,9 +122,13 @@ uint64_t emu_embed(const uint8_t *gray, uint8_t *stego, int F, int H, int W, dou
     const int dbl = make_qim(use ? delta : 1.0, &qp);
     // exact == 4: GUARDED - the cheap path wherever its error bound decides every pixel, the exact arithmetic elsewhere
     // (same routing as svs_embed_dev: one coefficient row, delta inside the guard's range; anything else is plain EXACT)
-    const bool guarded = exact == 4 && use > 0 && svs::rows_for(n) == 1 && delta >= SVS_GUARD_DELTA_MIN &&
-                         delta <= SVS_GUARD_DELTA_MAX;
+    // FAST (exact == 0) takes the same kernel for one coefficient row; with more rows it runs the FMA-factored kernels with
+    // their per-pixel guard.  Outside the delta range both modes run the exact kernels.
+    const bool in_range = delta >= SVS_GUARD_DELTA_MIN && delta <= SVS_GUARD_DELTA_MAX;
+    const bool guarded = (exact == 4 || exact == 0) && use > 0 && svs::rows_for(n) == 1 && in_range;
     if (guarded) svs::make_guard(delta, 1, &qp);
+    if (exact == 4 && !guarded) exact = 1;
+    if (exact == 0 && !in_range) exact = 1;
     if (use == 0) {
         if (n_bits > 0) {  // nothing consumed -> every block entered and round-tripped (either mode: svs_embed_dev)
             for (uint64_t gb = 0; gb < total; ++gb) {

@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     for name in names:
         assert hasattr(lib, name), name
     assert sorted(native.SIGNATURES) == names          # the binding covers the header, nothing more
-    assert lib.svs_abi_version() == native.ABI_VERSION == 2
+    assert lib.svs_abi_version() == native.ABI_VERSION == 3
 
 
 def test_header_is_plain_c_and_library_links_from_c(tmp_path):

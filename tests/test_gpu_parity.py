@@ -13,7 +13,7 @@ import os
 import numpy as np
 import pytest
 
-from testlib import (CONTRACT_POINTS, REPO, case_inputs, emu_embed, emu_extract, exact_tie_mask, golden_bits,
+from testlib import (CONTRACT_POINTS, GUARDED_POINTS, ORIGINAL_COVERS, REPO, case_inputs, emu_embed, emu_extract, exact_tie_mask, golden_bits,
                      natural_like, sha, single_frame_cases, structured_covers)
 from oracle import qim_dct_oracle as orc
 from svsdct import batch, native, synth
@@ -38,57 +38,62 @@ def test_device_is_gfx950():
     assert native.device_arch(0).startswith("gfx950")
 
 
-def test_exact_mode_golden_vectors_bit_for_bit(golden):
-    """EXACT mode (pocketfft-identical arithmetic): stego PIXELS, bit counts and extracted bits equal the
-    reference's in every golden case - ties, flat-block and delta <= 0 round-trip artefacts included."""
+@pytest.mark.parametrize("mode", ["exact", "guarded"])
+def test_exact_mode_golden_vectors_bit_for_bit(golden, mode):
+    """EXACT mode (pocketfft-identical arithmetic) and GUARDED mode (the streaming kernel with its rigorous guard): stego
+    PIXELS, bit counts and extracted bits equal the reference's in every golden case - ties, flat-block and delta <= 0
+    round-trip artefacts included."""
     arrays, meta = golden
     for name in single_frame_cases(meta):
         info, gray, payload = case_inputs(arrays, meta, name)
         delta, n_ac = info["delta"], info["n_ac"]
-        stego, used = batch.embed_frames(gray, delta, n_ac, payload, mode="exact")
+        stego, used = batch.embed_frames(gray, delta, n_ac, payload, mode=mode)
         assert used == info["used"], name
         assert sha(stego[0]) == info["stego_sha256"], name
         for src, tag in ((stego[0], "ext_stego"), (gray, "ext_cover")):
-            packed, n_bits = batch.extract_frames(src, delta, n_ac, mode="exact")
+            packed, n_bits = batch.extract_frames(src, delta, n_ac, mode=mode)
             assert n_bits == info[tag + "_len"], name
             assert np.array_equal(packed, arrays[f"{name}/{tag}"][:packed.size]), (name, tag)
-        _REPORT["exact/" + name] = {"pixels": int(gray.size), "pixels_differing_from_reference": 0}
+        _REPORT[mode + "/" + name] = {"pixels": int(gray.size), "pixels_differing_from_reference": 0}
     info = meta["cases"]["G8_stream"]
     frames = synth.synthetic_frames(3, 32, 48, seed=info["synth_seed"])
-    stego, used = batch.embed_frames(frames, info["delta"], info["n_ac"], arrays["G8_stream/payload"], mode="exact")
+    stego, used = batch.embed_frames(frames, info["delta"], info["n_ac"], arrays["G8_stream/payload"], mode=mode)
     assert used == info["used"]
     for k in range(3):
         assert np.array_equal(stego[k], arrays[f"G8_stream/stego{k}"])
 
 
+@pytest.mark.parametrize("mode", ["exact", "guarded"])
 @pytest.mark.parametrize("shape,n_ac,delta,frames", [((1080, 1920), 10, 8, 2), ((2160, 3840), 3, 8, 1),
-                                                      ((480, 640), 10, 20, 2), ((360, 640), 63, 4, 1)])
-def test_exact_mode_full_size_equals_oracle(shape, n_ac, delta, frames):
+                                                      ((480, 640), 10, 20, 2), ((360, 640), 63, 4, 1),
+                                                      ((1080, 1920), 7, 4, 1), ((720, 1280), 1, 20, 2)])
+def test_exact_mode_full_size_equals_oracle(shape, n_ac, delta, frames, mode):
     h, w = shape
     cover = synth.synthetic_frames(frames, h, w, seed=h ^ n_ac, lo=0, span=256)     # clipping included
     cap = batch.capacity_bits(frames, h, w, n_ac)
     payload = synth.synthetic_bits(cap - 17, seed=h)
-    stego, used = batch.embed_frames(cover, delta, n_ac, payload, mode="exact")
+    stego, used = batch.embed_frames(cover, delta, n_ac, payload, mode=mode)
     want, want_used = orc.batch_embed(cover, delta, payload, n_ac)
     assert used == want_used
     assert np.array_equal(stego, want)                                               # every pixel
-    packed, n_bits = batch.extract_frames(stego, delta, n_ac, mode="exact")
+    packed, n_bits = batch.extract_frames(stego, delta, n_ac, mode=mode)
     assert np.array_equal(np.unpackbits(packed, count=n_bits), orc.batch_extract_bits(want, delta, n_ac))
-    packed, n_bits = batch.extract_frames(cover, delta, n_ac, mode="exact")          # ties resolved as scipy does
+    packed, n_bits = batch.extract_frames(cover, delta, n_ac, mode=mode)          # ties resolved as scipy does
     assert np.array_equal(np.unpackbits(packed, count=n_bits), orc.batch_extract_bits(cover, delta, n_ac))
 
 
 _natural_like = natural_like
 
 
+@pytest.mark.parametrize("mode", ["exact", "guarded"])
 @pytest.mark.parametrize("n_ac,delta", [(3, 8), (10, 20), (7, 4)])
-def test_exact_mode_on_natural_like_content(n_ac, delta):
+def test_exact_mode_on_natural_like_content(n_ac, delta, mode):
     h, w = 1080, 1920
     cover = np.stack([_natural_like(h, w, s) for s in (1, 2)])
     cap = batch.capacity_bits(2, h, w, n_ac)
     payload = synth.synthetic_bits(cap, seed=n_ac)
     payload[: cap // 3] = 0                                # long zero runs: many blocks get no coefficient change
-    stego, used = batch.embed_frames(cover, delta, n_ac, payload, mode="exact")
+    stego, used = batch.embed_frames(cover, delta, n_ac, payload, mode=mode)
     want, want_used = orc.batch_embed(cover, delta, payload, n_ac)
     assert used == want_used and np.array_equal(stego, want)
     # the artefact is really there (and reproduced): flat blocks that changed although no coefficient did
@@ -107,7 +112,7 @@ def test_exact_mode_on_natural_like_content(n_ac, delta):
     for k in range(2):
         a, b = orc.psnr_u8(cover[k], fast[k]), orc.psnr_u8(cover[k], want[k])
         assert abs(a - b) <= PSNR_TOL_DB, (k, a, b)
-        _REPORT[f"natural_like_n{n_ac}_d{delta}_frame{k}"] = {
+        _REPORT[f"natural_like_n{n_ac}_d{delta}_frame{k}_{mode}"] = {
             "pixels": h * w, "pixels_differing_from_reference": int((fast[k] != want[k]).sum()), "psnr": a,
             "psnr_reference": b}
 
@@ -118,8 +123,10 @@ def test_fast_mode_contract_on_structured_content(n_ac, delta):
     within 0.01 dB of the oracle's, identical to the CPU build of the kernel header (which the CPU tier checks on the same
     content), the reference's receiver reads the same bits from either stego frame, FAST extraction of stego, reference
     stego and never-embedded cover equals the oracle's on every bit."""
-    h, w = 1080, 1920
-    for name, cover in structured_covers(h, w).items():
+    covers = {k: v for k, v in structured_covers(1080, 1920).items() if k in ORIGINAL_COVERS}
+    covers.update({k: v for k, v in structured_covers(544, 960).items() if k not in ORIGINAL_COVERS})   # VERDICT r02 next #3
+    for name, cover in covers.items():
+        h, w = cover.shape
         cap = batch.capacity_bits(1, h, w, n_ac)
         payload = synth.synthetic_bits(cap, seed=n_ac * 100 + delta)
         stego, used = batch.embed_frames(cover, delta, n_ac, payload, mode="fast")
@@ -149,6 +156,57 @@ def test_fast_mode_contract_on_structured_content(n_ac, delta):
     planes = Planes.contiguous(f, 256, 512)
     assert batch.embed_device(d_frames.ptr, d_frames.ptr, planes, delta, n_ac, d_bits.ptr, 0, payload.size) == payload.size
     assert np.array_equal(d_frames.get().reshape(cover.shape), want)
+
+
+@pytest.mark.parametrize("n_ac,delta", GUARDED_POINTS)
+def test_guarded_mode_equals_reference_on_structured_content(n_ac, delta):
+    """the streaming kernel with its rigorous guard is the reference, pixel for pixel, on 14 content
+    classes (flat, letterboxed, one-dimensional, posterised, text-like, dark / bright noise, exact cancellations ...) at
+    every setting incl. the ends of its delta range; the share of blocks it redid exactly is recorded per class."""
+    lib = native.load()
+    lib.svs_guard_counter_set.restype = C.c_int
+    lib.svs_guard_counter_set.argtypes = [C.c_void_p]
+    h, w = 544, 960
+    d_cnt = _Dev(8)
+    for name, cover in structured_covers(h, w).items():
+        cap = batch.capacity_bits(1, h, w, n_ac)
+        payload = synth.synthetic_bits(cap, seed=n_ac * 100 + int(delta))
+        native.check(lib.svs_memset(d_cnt.ptr, 0, 8, None), "memset")
+        native.check(lib.svs_stream_synchronize(None), "sync")
+        lib.svs_guard_counter_set(d_cnt.ptr)
+        try:
+            stego, used = batch.embed_frames(cover, delta, n_ac, payload, mode="guarded")
+        finally:
+            lib.svs_guard_counter_set(None)
+        _, ref, ref_used = orc.frame_embed(cover, delta, payload, n_ac)
+        assert used == ref_used and np.array_equal(stego[0], ref), name
+        fast, used_f = batch.embed_frames(cover, delta, n_ac, payload, mode="fast")      # n <= 7: the same launch
+        assert used_f == ref_used and np.array_equal(fast[0], ref), name
+        _REPORT[f"guarded/{name}_n{n_ac}_d{delta:g}"] = {
+            "pixels": h * w, "pixels_differing_from_reference": 0,
+            "blocks_redone_exactly_share": int(d_cnt.get(8, np.uint64)[0]) / (cap // n_ac)}
+
+
+@pytest.mark.parametrize("f,h,w,n_ac,delta", [(600, 2160, 3840, 3, 8.0), (300, 1080, 1920, 7, 4.0), (150, 4320, 7680, 1, 16.0)])
+def test_guarded_mode_full_batch_equals_exact_kernel_on_device(f, h, w, n_ac, delta):
+    """BASELINE batch sizes, device-resident: the streaming kernel's output has zero squared difference to the
+    lane-per-block pocketfft kernel's on every frame (5 Gpixel per case), in place as well."""
+    lib = native.load()
+    planes = Planes.contiguous(f, h, w)
+    cap = batch.capacity_bits(f, h, w, n_ac)
+    nbytes = (cap + 7) // 8 + 8
+    d_gray, d_a, d_b = _Dev(f * h * w), _Dev(f * h * w), _Dev(f * h * w)
+    d_pay, d_sse = _Dev(nbytes), _Dev(8 * f)
+    native.check(lib.svs_fill_synthetic_dev(d_gray.ptr, C.byref(planes), 20250620, 0, 0, 256, None), "fill")   # clipping included
+    native.check(lib.svs_memset(d_pay.ptr, 0, nbytes, None), "memset")
+    native.check(lib.svs_fill_bits_dev(d_pay.ptr, cap - 5, 20250620, 0, None), "bits")
+    assert batch.embed_device(d_gray.ptr.value, d_a.ptr.value, planes, delta, n_ac, d_pay.ptr.value, 0, cap - 5, mode="exact") == cap - 5
+    assert batch.embed_device(d_gray.ptr.value, d_b.ptr.value, planes, delta, n_ac, d_pay.ptr.value, 0, cap - 5, mode="guarded") == cap - 5
+    native.check(lib.svs_frame_sse_dev(d_a.ptr, d_b.ptr, C.byref(planes), d_sse.ptr, None), "sse")
+    assert int(d_sse.get(8 * f, np.uint64).sum()) == 0
+    assert batch.embed_device(d_gray.ptr.value, d_gray.ptr.value, planes, delta, n_ac, d_pay.ptr.value, 0, cap - 5, mode="guarded") == cap - 5
+    native.check(lib.svs_frame_sse_dev(d_a.ptr, d_gray.ptr, C.byref(planes), d_sse.ptr, None), "sse")
+    assert int(d_sse.get(8 * f, np.uint64).sum()) == 0
 
 
 def test_golden_vectors(golden):
@@ -366,6 +424,19 @@ def test_extreme_quantiser_steps():
             fast, fast_used = batch.embed_frames(frames, delta, n_ac, bits, mode="fast")
             want, want_used = emu_embed(frames, delta, n_ac, bits)
             assert fast_used == want_used and np.array_equal(fast, want), (delta, n_ac)
+            if not (0.25 <= delta <= 4096):            # outside the streaming kernels' delta range FAST runs the exact kernels
+                assert np.array_equal(fast, ref), (delta, n_ac)
+    # FAST against the ORACLE at small delta on a frame of real size (the header's delta domain)
+    big = synth.synthetic_frames(1, 544, 960, seed=77, lo=0, span=256)
+    for delta in (0.02, 0.1, 0.5, 1.0):
+        for n_ac in (3, 10):
+            bits = synth.synthetic_bits(batch.capacity_bits(1, 544, 960, n_ac), seed=3)
+            ref, _ = orc.batch_embed(big, delta, bits, n_ac)
+            fast, _ = batch.embed_frames(big, delta, n_ac, bits, mode="fast")
+            a, b = orc.psnr_u8(big[0], fast[0]), orc.psnr_u8(big[0], ref[0])
+            assert abs(a - b) <= PSNR_TOL_DB, (delta, n_ac, a, b)
+            if delta < 0.25 or n_ac <= 7:
+                assert np.array_equal(fast, ref), (delta, n_ac)
 
 
 def test_baseline_config4_shape_clips_sharded_by_frame():
@@ -761,10 +832,12 @@ def test_drop_in_operator_matches_reference_contract(golden):
     assert cs.proses_frame_qim_dct(s, "extract", 7.5)[:used] == orc.frame_extract(s, 7.5, 63)[:used]
 
 
-def test_replay_map_is_reused_across_calls_sizes_and_streams():
-    """The replay map is one buffer per stream, kept all-zero between calls by the replay pass and grown on demand.
-    Calls of different sizes, block mappings (one / two blocks per lane) and content (all flagged, nothing flagged) are
-    interleaved on two streams; every result must equal the one-shot result of the CPU build of the kernel header."""
+def test_embed_calls_are_stateless_across_sizes_streams_and_host_threads():
+    """The embed kernels keep nothing between calls (undecided blocks are redone inside the launch), so calls of different
+    sizes, block mappings (one / two blocks per lane) and content (every block of a wave undecided, a few, none) can be
+    interleaved on two streams, and the host-pointer entry points can run concurrently from several host threads
+    (the round-2 replay map was shared per device).  Every result must equal the CPU build of the header."""
+    import threading
     lib = native.load()
     rng = np.random.default_rng(12)
     streams = []
@@ -773,32 +846,61 @@ def test_replay_map_is_reused_across_calls_sizes_and_streams():
         native.check(lib.svs_stream_create(C.byref(st)), "stream")
         streams.append(st)
     shapes = [(2, 64, 96), (5, 128, 256), (1, 8, 8), (3, 72, 88), (7, 256, 512), (2, 64, 96), (1, 40, 24)]   # 88/8, 24/8 odd
-    n_ac, delta = 3, 8
-    jobs = []
-    for k, (f, h, w) in enumerate(shapes * 2):
+
+    def make(k, f, h, w, n_ac):
         kind = k % 3
         if kind == 0:
-            cover = np.full((f, h, w), 100 + k, np.uint8)                    # every block flagged
+            cover = np.full((f, h, w), 100 + k, np.uint8)                    # flat: many undecided blocks per wave
         elif kind == 1:
-            cover = rng.integers(16, 240, (f, h, w), dtype=np.uint8)         # nothing flagged
+            cover = rng.integers(16, 240, (f, h, w), dtype=np.uint8)         # noise: a few per cent
         else:
             cover = rng.integers(16, 240, (f, h, w), dtype=np.uint8)
-            cover[:, : h // 2] = 200                                          # half flagged
+            cover[:, : h // 2] = 200
         off = int(rng.integers(0, 100))                                       # stream starts at a bit offset
-        short = int(rng.integers(0, 3 * n_ac))                                # ... and ends inside the last blocks
-        bits = rng.integers(0, 2, off + batch.capacity_bits(f, h, w, n_ac) - short).astype(np.uint8)
-        d_in, d_out, d_bits = _Dev(cover.nbytes), _Dev(cover.nbytes), _Dev(batch.pack_bits(bits).nbytes)
-        d_in.put(cover)
-        d_bits.put(batch.pack_bits(bits))
-        st = streams[k % 2]
-        used = batch.embed_device(d_in.ptr.value, d_out.ptr.value, Planes.contiguous(f, h, w), delta, n_ac, d_bits.ptr.value, off,
-                                  bits.size - off, stream=st.value, mode="fast")
-        assert used == bits.size - off
-        jobs.append((cover, bits, off, d_in, d_out, d_bits))
-    for st in streams:
-        native.check(lib.svs_stream_synchronize(st), "sync")
-    for cover, bits, off, d_in, d_out, d_bits in jobs:
-        want, _ = emu_embed(cover, delta, n_ac, bits, bit_offset=off)
-        assert np.array_equal(d_out.get().reshape(cover.shape), want), cover.shape
+        cap = batch.capacity_bits(f, h, w, n_ac)
+        short = min(int(rng.integers(0, 3 * n_ac)), cap - 1)                  # ... and ends inside the last blocks
+        bits = rng.integers(0, 2, off + cap - short).astype(np.uint8)
+        return cover, bits, off
+
+    for n_ac, delta, mode in ((3, 8, "fast"), (1, 8, "guarded"), (10, 8, "fast")):
+        jobs = []
+        for k, (f, h, w) in enumerate(shapes * 2):
+            cover, bits, off = make(k, f, h, w, n_ac)
+            d_in, d_out, d_bits = _Dev(cover.nbytes), _Dev(cover.nbytes), _Dev(batch.pack_bits(bits).nbytes)
+            d_in.put(cover)
+            d_bits.put(batch.pack_bits(bits))
+            st = streams[k % 2]
+            used = batch.embed_device(d_in.ptr.value, d_out.ptr.value, Planes.contiguous(f, h, w), delta, n_ac,
+                                      d_bits.ptr.value, off, bits.size - off, stream=st.value, mode=mode)
+            assert used == bits.size - off
+            jobs.append((cover, bits, off, d_in, d_out, d_bits))
+        for st in streams:
+            native.check(lib.svs_stream_synchronize(st), "sync")
+        for cover, bits, off, d_in, d_out, d_bits in jobs:
+            want, _ = emu_embed(cover, delta, n_ac, bits, bit_offset=off, exact=4 if mode == "guarded" else 0)
+            assert np.array_equal(d_out.get().reshape(cover.shape), want), (cover.shape, n_ac)
     for st in streams:
         native.check(lib.svs_stream_destroy(st), "destroy")
+
+    # four host threads, each looping over its own frames through the host-pointer API (ctypes releases the GIL)
+    work = [make(k, *shapes[(k + 1) % len(shapes)], 3) for k in range(4)]
+    wants = [emu_embed(c, 8, 3, b, bit_offset=o)[0] for c, b, o in work]
+    failures = []
+
+    def run(i):
+        try:
+            native.ensure_device(0)
+            cover, bits, off = work[i]
+            for _ in range(6):
+                got, used = batch.embed_frames(cover, 8, 3, bits, bit_offset=off, mode="fast")
+                if used != bits.size - off or not np.array_equal(got, wants[i]):
+                    failures.append(i)
+        except Exception as exc:   # noqa: BLE001
+            failures.append((i, repr(exc)))
+
+    threads = [threading.Thread(target=run, args=(i,)) for i in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not failures, failures

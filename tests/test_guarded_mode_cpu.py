@@ -1,0 +1,151 @@
+"""CPU tier: GUARDED mode (csrc/svs_block.hpp embed_block_guarded + tools/guard_bound.py).
+
+The guarded path keeps the cheap prediction  floor(pixel + sparse inverse of the coefficient changes)  only where a
+rigorous bound on the float32 noise of the reference's own round trip (config_and_setup.py:135,166-171) proves the
+reference truncates to the same byte; undecided blocks go through the pocketfft-identical arithmetic.  So the mode must be
+BIT-IDENTICAL to the reference on any input - checked here on the CPU build of the kernel header against the golden
+vectors, the oracle, and the EXACT mode, and the bound itself against scipy's float32 transforms."""
+import importlib.util
+import os
+import re
+
+import numpy as np
+import pytest
+from hypothesis import given, settings, strategies as st
+
+from testlib import (CSRC, GUARDED_POINTS, REPO, case_inputs, emu_embed, sha, single_frame_cases, structured_covers)
+from oracle import qim_dct_oracle as orc
+from svsdct import synth
+
+
+def _tool():
+    spec = importlib.util.spec_from_file_location("guard_bound", os.path.join(REPO, "tools", "guard_bound.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def _header_constants():
+    text = open(os.path.join(CSRC, "svs_block.hpp")).read()
+    return {name: float(re.search(r"#define\s+%s\s+([0-9.eE+-]+)" % name, text).group(1))
+            for name in ("SVS_GUARD_KDC", "SVS_GUARD_KE", "SVS_GUARD_KD_U1", "SVS_GUARD_KD_U2")}
+
+
+def test_header_constants_cover_the_derived_bound():
+    """The constants compiled into the kernels are at least what tools/guard_bound.py derives from the operation sequences
+    of svs::pf (and not more than 1 % above: a stale, overly generous constant would only cost speed, but say so)."""
+    gb = _tool()
+    have = _header_constants()
+    k7 = gb.analyse(7, verbose=False)
+    for name, val in (("SVS_GUARD_KDC", k7["kdc"]), ("SVS_GUARD_KE", k7["ke"]), ("SVS_GUARD_KD_U1", k7["kd"])):
+        assert val <= have[name] <= val * 1.01 + 1e-3, (name, have[name], val)
+    assert k7["ke_lo"] > 0.5 * k7["ke"]      # the Cauchy-Schwarz bound on the (2 -> 1) norm is within 2x of a lower bound
+
+
+def test_bound_holds_on_scipy_float32_round_trips():
+    """|out - pred| <= BETA(mean, residual, delta) on 8 content classes x 3 settings with the reference's own arithmetic
+    (scipy float32) against float64 (tools/guard_bound.py::empirical asserts it per block)."""
+    gb = _tool()
+    have = _header_constants()
+    k = dict(kdc=have["SVS_GUARD_KDC"], ke=have["SVS_GUARD_KE"], kd=have["SVS_GUARD_KD_U1"])
+    for n, delta in ((3, 8), (7, 4), (3, 100)):
+        for kind, emax, bmean, slack in gb.empirical(k, 3000, n, delta):
+            assert slack >= 1.0, (kind, n, delta, slack)
+
+
+@pytest.mark.parametrize("exact", [1, 4])
+def test_golden_vectors_bit_for_bit(golden, exact):
+    arrays, meta = golden
+    for name in single_frame_cases(meta):
+        info, gray, payload = case_inputs(arrays, meta, name)
+        stego, used = emu_embed(gray, info["delta"], info["n_ac"], payload, exact=exact)
+        assert used == info["used"], name
+        assert sha(stego[0]) == info["stego_sha256"], name
+    info = meta["cases"]["G8_stream"]
+    frames = synth.synthetic_frames(3, 32, 48, seed=info["synth_seed"])
+    stego, used = emu_embed(frames, info["delta"], info["n_ac"], arrays["G8_stream/payload"], exact=exact)
+    assert used == info["used"]
+    for k in range(3):
+        assert np.array_equal(stego[k], arrays[f"G8_stream/stego{k}"])
+
+
+@pytest.mark.parametrize("n_ac,delta", GUARDED_POINTS)
+def test_guarded_equals_exact_on_structured_content(n_ac, delta):
+    """14 content classes (flat, letterboxed, one-dimensional, posterised, text-like, dark / bright noise, exact
+    cancellations ...): identical to EXACT and to the oracle; the share of blocks the guard hands to the exact arithmetic
+    is recorded per class."""
+    h, w = 272, 480
+    shares = {}
+    for name, cover in structured_covers(h, w).items():
+        cap = (h // 8) * (w // 8) * n_ac
+        for fill in (None, 0):
+            payload = synth.synthetic_bits(cap, seed=n_ac * 100 + int(delta)) if fill is None else np.zeros(cap, np.uint8)
+            redone = []
+            got, used = emu_embed(cover, delta, n_ac, payload, exact=4, replayed=redone)
+            want, want_used = emu_embed(cover, delta, n_ac, payload, exact=1)
+            assert used == want_used and np.array_equal(got, want), (name, fill)
+            _, ref, ref_used = orc.frame_embed(cover, delta, payload, n_ac)
+            assert used == ref_used and np.array_equal(got[0], ref), (name, fill)
+            if fill is None:
+                shares[name] = redone[0] / (cap // n_ac)
+    if 1 <= delta <= 100:                                                # the GUI's range (app.py:232)
+        assert shares["ramp"] < 0.2 and shares["dark_noise_0_3"] < 0.2  # the guard decides most blocks of ordinary content
+
+
+def test_noise_content_share_and_partial_budgets():
+    frames = synth.synthetic_frames(2, 272, 480, seed=9)
+    cap = 2 * 34 * 60 * 3
+    payload = synth.synthetic_bits(cap, seed=9)
+    redone = []
+    got, used = emu_embed(frames, 8, 3, payload, exact=4, replayed=redone)
+    want, _ = emu_embed(frames, 8, 3, payload, exact=1)
+    assert np.array_equal(got, want)
+    assert 0.005 < redone[0] / (cap // 3) < 0.05        # about 2.3 % on hash noise (16 * BETA)
+    rng = np.random.default_rng(4)
+    small = rng.integers(0, 256, (2, 32, 64), dtype=np.uint8)
+    for n_ac, delta in ((3, 8), (7, 4), (1, 20)):
+        cap = 2 * 4 * 8 * n_ac
+        for n_bits in (cap, cap - 1, n_ac, n_ac + 1, 2 * n_ac - 1, 5 * n_ac + 2, 0, 1):
+            bits = rng.integers(0, 2, 11 + n_bits).astype(np.uint8)
+            a, ua = emu_embed(small, delta, n_ac, bits, bit_offset=11, exact=4)
+            b, ub = emu_embed(small, delta, n_ac, bits, bit_offset=11, exact=1)
+            assert ua == ub and np.array_equal(a, b), (n_ac, delta, n_bits)
+
+
+def test_outside_the_guarded_domain_the_exact_arithmetic_runs():
+    """n_ac >= 8, delta outside [0.25, 4096], delta <= 0: the flag is still valid and the result is the reference's"""
+    rng = np.random.default_rng(6)
+    frames = rng.integers(0, 256, (1, 48, 64), dtype=np.uint8)
+    for n_ac, delta in ((10, 8), (63, 4), (3, 0.01), (3, 1e5), (3, 0), (0, 8), (8, 8)):
+        cap = 6 * 8 * max(0, min(n_ac, 63))
+        bits = rng.integers(0, 2, max(cap, 1)).astype(np.uint8)
+        redone = []
+        a, ua = emu_embed(frames, delta, n_ac, bits, exact=4, replayed=redone)
+        b, ub = emu_embed(frames, delta, n_ac, bits, exact=1)
+        assert ua == ub and np.array_equal(a, b) and redone[0] == 0, (n_ac, delta)
+
+
+@settings(max_examples=60, deadline=None)
+@given(st.integers(0, 2 ** 32 - 1), st.integers(1, 7), st.sampled_from([0.25, 0.5, 1, 2, 3, 4, 7.5, 8, 16, 20, 100, 1000]),
+       st.sampled_from(["full", "narrow", "flat", "columns", "rows", "binary"]))
+def test_guarded_equals_oracle_hypothesis(seed, n_ac, delta, kind):
+    rng = np.random.default_rng(seed)
+    h, w = 8 * int(rng.integers(1, 5)), 8 * int(rng.integers(1, 9))
+    if kind == "full":
+        cover = rng.integers(0, 256, (h, w), dtype=np.uint8)
+    elif kind == "narrow":
+        lo = int(rng.integers(0, 250))
+        cover = rng.integers(lo, lo + 6, (h, w), dtype=np.uint8)
+    elif kind == "flat":
+        cover = np.full((h, w), int(rng.integers(0, 256)), np.uint8)
+    elif kind == "columns":
+        cover = np.repeat(rng.integers(0, 256, (1, w), dtype=np.uint8), h, axis=0)
+    elif kind == "rows":
+        cover = np.repeat(rng.integers(0, 256, (h, 1), dtype=np.uint8), w, axis=1)
+    else:
+        cover = (rng.integers(0, 2, (h, w)) * 255).astype(np.uint8)
+    cap = (h // 8) * (w // 8) * n_ac
+    bits = rng.integers(0, 2, int(rng.integers(0, cap + 3))).astype(np.uint8)
+    got, used = emu_embed(cover, delta, n_ac, bits, exact=4)
+    _, ref, ref_used = orc.frame_embed(cover, delta, bits, n_ac)
+    assert used == ref_used and np.array_equal(got[0], ref)

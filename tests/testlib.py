@@ -27,8 +27,19 @@ def natural_like(h, w, seed):
 
 def structured_covers(h, w, seed=0):
     """name -> gray frame with structure that makes MANY blocks' coefficient changes structurally zero or integer-valued
-    (VERDICT r01 'What's weak' #1): there the reference's output is decided by pocketfft's round-trip noise."""
+    (VERDICT r01 'What's weak' #1): there the reference's output is decided by pocketfft's round-trip noise.  The second
+    half of the list are the content classes of the round-2 review's adversarial probe (VERDICT r02 next #3)."""
     rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:h, 0:w]
+    text = np.repeat(np.repeat(rng.integers(0, 2, (h // 4 + 1, w // 4 + 1), dtype=np.uint8), 4, axis=0), 4, axis=1)[:h, :w]
+    abba = np.array([40, 200, 200, 40], np.uint8)[(np.arange(w) % 4)]
+    # blocks base + outer(r, c) with sum r = sum c = 0: every row-0 / column-0 AC coefficient vanishes by exact cancellation
+    outer = np.empty((h, w), np.int64)
+    for by in range(h // 8):
+        for bx in range(w // 8):
+            r = rng.integers(-5, 6, 8); r[7] -= r.sum()
+            c = rng.integers(-5, 6, 8); c[7] -= c.sum()
+            outer[8 * by: 8 * by + 8, 8 * bx: 8 * bx + 8] = 128 + np.clip(np.outer(r, c), -100, 100)
     return {
         "natural_like": natural_like(h, w, seed + 1),
         "flat_128": np.full((h, w), 128, np.uint8),
@@ -38,12 +49,23 @@ def structured_covers(h, w, seed=0):
                                           rng.integers(16, 240, (h - h // 2, w), dtype=np.uint8)]),
         "checker_8": ((np.add.outer(np.arange(h) // 8, np.arange(w) // 8) % 2) * 200 + 20).astype(np.uint8),
         "ramp": np.repeat((np.arange(w) // 4 % 256).astype(np.uint8)[None], h, axis=0),
+        "dark_noise_0_3": rng.integers(0, 4, (h, w), dtype=np.uint8),
+        "bright_noise_252_255": rng.integers(252, 256, (h, w), dtype=np.uint8),
+        "posterised_sinusoid": (np.round((128 + 100 * np.sin(xx / 23.0) * np.cos(yy / 17.0)) / 32) * 32).clip(0, 255).astype(np.uint8),
+        "text_4x4_binary": (text * 255).astype(np.uint8),
+        "abba_stripes": np.repeat(abba[None], h, axis=0),
+        "lsb_noise_on_flat": (100 + rng.integers(0, 2, (h, w))).astype(np.uint8),
+        "outer_product_blocks": outer.clip(0, 255).astype(np.uint8),
     }
 
 
+ORIGINAL_COVERS = ("natural_like", "flat_128", "constant_rows", "constant_columns", "half_letterbox", "checker_8", "ramp")
+
 # (n_ac, delta) points of the FAST-mode contract checks on structured content plus the settings at
-# which the index-4 / two-row coincidences are largest
-CONTRACT_POINTS = [(3, 8), (3, 16), (7, 4), (10, 20), (4, 8), (8, 4), (8, 2)]
+# which the index-4 / two-row coincidences are largest; (1, 8), (16, 8), (36, 8), (63, 4) added after VERDICT r02 next #3
+CONTRACT_POINTS = [(3, 8), (3, 16), (7, 4), (10, 20), (4, 8), (8, 4), (8, 2), (1, 8), (16, 8), (36, 8), (63, 4), (9, 8)]
+# (n_ac, delta) points of the GUARDED-mode identity checks (one coefficient row; the ends of the delta range included)
+GUARDED_POINTS = [(3, 8), (1, 8), (7, 4), (4, 8), (3, 16), (5, 0.5), (2, 0.25), (3, 100), (7, 4096), (6, 7.3)]
 
 
 def sha(a):
