@@ -186,7 +186,7 @@ int launch_extract(int rows, uint64_t total, hipStream_t st, const uint8_t *gray
     // (profiles/r01_ab_quant_exact.txt).  The same specialisation of the embed kernel measured SLOWER (-13 % at
     // 600 x 4K, n = 10) and n = 3 gains nothing (HBM-bound), so those stay on the run-time-n kernels.
     const bool fixed_n = env_chunk("SVS_FIXED_N", 1) != 0;   // experiment knob
-    const uint32_t lds_pad = lds_pad_for(env_chunk("SVS_EXTRACT_WG_PER_CU", extract_wg_per_cu(rows)), 4096);
+    const uint32_t lds_pad = lds_pad_for(env_chunk("SVS_EXTRACT_WG_PER_CU", extract_wg_per_cu(rows)), 18432);
     if (fixed_n && g.n_ac == 10) {
         hipLaunchKernelGGL((svs::extract_kernel<2, QM, BPL, 10>), grid, dim3(SVS_WG), lds_pad, st, gray, g, qp, out, out_bytes);
         SVS_HIP(hipGetLastError());

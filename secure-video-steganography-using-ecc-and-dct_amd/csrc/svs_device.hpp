@@ -159,17 +159,107 @@ __device__ __forceinline__ void emit_wave_bits(uint32_t *mine, uint32_t lane, ui
     }
 }
 
+struct GuardEntry {
+    uint32_t px[16];   // rows as (low dword, high dword) pairs: the original pixels in, the exact stego pixels out
+    uint32_t hi, lo;   // payload window of the block
+    uint32_t nb;       // bits the block takes
+    uint32_t pad;
+};
+#define SVS_GUARD_TILE 72   // floats per block of the transposition tile: element (i, j) at 9 i + j; 72 = 8 (mod 64) keeps the
+                            // eight groups of a wave on different LDS banks in both directions
+
+// FAST extraction, second path: a block with a quantiser input inside the per-block tie margin (svs_block.hpp SVS_TIE2_*)
+// gets the pocketfft-identical forward transform - by EIGHT LANES PER BLOCK, as in the embed kernels' replay: lane r of a
+// group transforms column r, then row r, then takes coefficient column r and quantises its coefficients k = 8 u + r of the
+// rows u the payload uses; the bits are ORed into the entry.  About 200 instructions per pass of 8 blocks, against 580 for
+// every wave that had such a lane when the whole block was redone by its own lane (round 2).
+template <int QM>
+__device__ __forceinline__ void extract_replay8(GuardEntry *e, float *t, uint32_t r, uint32_t n, const QimParams &qp) {
+    float a[8], b[8];
+    {
+        const uint32_t sh = 8u * (r & 3u), half = r >> 2;
+#pragma unroll
+        for (int y = 0; y < 8; ++y) a[y] = (float)((e->px[2 * y + half] >> sh) & 0xffu);
+    }
+    pf::dct2_8(a, b);                       // b[u] = V[u][r]
+#pragma unroll
+    for (int u = 0; u < 8; ++u) t[9 * u + r] = b[u];
+    wave_lds_fence();
+#pragma unroll
+    for (int x = 0; x < 8; ++x) a[x] = t[9 * r + x];   // V[r][x]
+    wave_lds_fence();
+    pf::dct2_8(a, b);                       // b[v] = D[r][v]
+#pragma unroll
+    for (int v = 0; v < 8; ++v) t[9 * r + v] = b[v];
+    wave_lds_fence();
+    uint32_t hi = 0, lo = 0;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const uint32_t k = 8u * u + r;
+        if (k >= 1u && k <= n) {            // no lane of the wave enters for rows the payload does not use
+            const uint32_t bit = (uint32_t)quant_index<QM>(t[9 * u + r], qp) & 1u;
+            const uint32_t i = k - 1u;
+            if (i < 32u) hi |= bit << (31u - i);
+            else lo |= bit << (63u - i);
+        }
+    }
+    if (hi) atomicOr(&e->hi, hi);
+    if (lo) atomicOr(&e->lo, lo);
+}
+
+// the wave's tie blocks through the worklist (CAP entries per round); on return hi/lo of those blocks hold the reference's bits
+template <int QM, bool TWO, int CAP>
+__device__ __forceinline__ void extract_phase2(GuardEntry *entries, float *tile, uint32_t lane, uint32_t n, const QimParams &qp,
+                                               bool tie_a, const uint32_t (&ax)[8], const uint32_t (&ay)[8], uint32_t &hi_a, uint32_t &lo_a,
+                                               bool tie_b, const uint32_t (&bx)[8], const uint32_t (&by)[8], uint32_t &hi_b, uint32_t &lo_b) {
+    const uint64_t mask_a = __ballot(tie_a);
+    const uint64_t mask_b = TWO ? __ballot(tie_b) : 0ull;
+    if ((mask_a | mask_b) == 0) return;     // wave-uniform; always the case on stego frames
+    const uint32_t n_a = (uint32_t)__popcll(mask_a), total = n_a + (uint32_t)__popcll(mask_b);
+    const uint32_t rank_a = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask_a >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask_a, 0u));
+    const uint32_t rank_b = n_a + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask_b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask_b, 0u));
+    for (uint32_t base = 0; base < total; base += (uint32_t)CAP) {   // wave-uniform
+        const bool mine_a = tie_a && rank_a >= base && rank_a < base + (uint32_t)CAP;
+        const bool mine_b = TWO && tie_b && rank_b >= base && rank_b < base + (uint32_t)CAP;
+        if (mine_a) {
+            GuardEntry *e = &entries[rank_a - base];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) { e->px[2 * r] = ax[r]; e->px[2 * r + 1] = ay[r]; }
+            e->hi = 0; e->lo = 0;
+        }
+        if (mine_b) {
+            GuardEntry *e = &entries[rank_b - base];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) { e->px[2 * r] = bx[r]; e->px[2 * r + 1] = by[r]; }
+            e->hi = 0; e->lo = 0;
+        }
+        wave_lds_fence();
+        const uint32_t todo = min(total - base, (uint32_t)CAP);
+        for (uint32_t first = 0; first < todo; first += 8u) {
+            const uint32_t idx = first + (lane >> 3);
+            if (idx < todo) extract_replay8<QM>(&entries[idx], tile + (lane >> 3) * SVS_GUARD_TILE, lane & 7u, n, qp);
+        }
+        wave_lds_fence();
+        if (mine_a) { hi_a = entries[rank_a - base].hi; lo_a = entries[rank_a - base].lo; }
+        if (mine_b) { hi_b = entries[rank_b - base].hi; lo_b = entries[rank_b - base].lo; }
+        wave_lds_fence();
+    }
+}
+
 // ---------------------------------------------------------------------------------------
 // EXTRACT: one lane = BPL adjacent blocks; a wavefront's 64*BPL blocks produce exactly n*BPL
 // aligned 64-bit words of the packed stream (stream bit = global block * n + i), assembled through
 // a wave-private LDS byte array and written with plain dword stores - no atomics, no pre-zeroed
 // output.  HBM traffic per block: 64 B read + n bits written.
 // ---------------------------------------------------------------------------------------
+#define SVS_EXTRACT_CAP 16   // worklist entries per wave and round of the extract kernels
 template <int U, int QM, int BPL, int NFIX = 0>
 __global__ __launch_bounds__(SVS_WG) void extract_kernel(const uint8_t *__restrict__ gray, const Geometry g,
                                                       const QimParams qp, uint8_t *__restrict__ out,
                                                       const uint64_t out_bytes) {
     __shared__ uint32_t flags[SVS_WG / 64][SVS_WAVE_BITS_DWORDS(BPL)];
+    __shared__ GuardEntry entries[SVS_WG / 64][SVS_EXTRACT_CAP];
+    __shared__ float tiles[SVS_WG / 64][8 * SVS_GUARD_TILE];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t tile = tile_id(g.xcd_chunk);
     const uint32_t gblock = (tile * (uint32_t)SVS_WG + threadIdx.x) * BPL;
@@ -177,46 +267,24 @@ __global__ __launch_bounds__(SVS_WG) void extract_kernel(const uint8_t *__restri
 
     // each block's bits, MSB first: bit i at position 63-i of hi:lo
     uint32_t hi_a = 0, lo_a = 0, hi_b = 0, lo_b = 0;
+    uint32_t ax[8], ay[8], bx[8], by[8];
+    bool tie_a = false, tie_b = false;
     if (gblock < g.total_blocks) {
-        const uint8_t *src = gray + block_offset(gblock, g);
-        bool tie_a, tie_b = false;
-        {
-            typename RowVec<BPL>::type v[8];
-            load_rows<BPL>(src, g.row_pitch, v);
-            uint32_t ax[8], ay[8];
+        typename RowVec<BPL>::type v[8];
+        load_rows<BPL>(gray + block_offset(gblock, g), g.row_pitch, v);
 #pragma unroll
-            for (int r = 0; r < 8; ++r) { ax[r] = v[r].x; ay[r] = v[r].y; }
-            tie_a = extract_block<U, QM, NFIX>(ax, ay, n, qp, hi_a, lo_a);
-            if constexpr (BPL == 2) {
-                uint32_t bx[8], by[8];
-#pragma unroll
-                for (int r = 0; r < 8; ++r) { bx[r] = v[r].z; by[r] = v[r].w; }
-                tie_b = extract_block<U, QM, NFIX>(bx, by, n, qp, hi_b, lo_b);
-            }
-        }
-        // A quantiser input within the forward error bound of a rounding tie (svs_block.hpp, SVS_TIE_SLOPE): redo the
-        // block with the pocketfft-identical transform.  Waves without such a lane branch over this (execz); the rows
-        // are fetched again rather than kept alive in 16 registers.  Never taken on stego frames at delta >= 8.
-        if (tie_a) {
-            typename RowVec<1>::type v[8];
-            load_rows<1>(src, g.row_pitch, v);
-            uint32_t ax[8], ay[8];
-#pragma unroll
-            for (int r = 0; r < 8; ++r) { ax[r] = v[r].x; ay[r] = v[r].y; }
-            extract_block_exact<U, QM>(ax, ay, n, qp, hi_a, lo_a);
-        }
+        for (int r = 0; r < 8; ++r) { ax[r] = v[r].x; ay[r] = v[r].y; }
+        tie_a = extract_block<U, QM, NFIX>(ax, ay, n, qp, hi_a, lo_a);
         if constexpr (BPL == 2) {
-            if (tie_b) {
-                typename RowVec<1>::type v[8];
-                load_rows<1>(src + 8, g.row_pitch, v);
-                uint32_t bx[8], by[8];
 #pragma unroll
-                for (int r = 0; r < 8; ++r) { bx[r] = v[r].x; by[r] = v[r].y; }
-                extract_block_exact<U, QM>(bx, by, n, qp, hi_b, lo_b);
-            }
+            for (int r = 0; r < 8; ++r) { bx[r] = v[r].z; by[r] = v[r].w; }
+            tie_b = extract_block<U, QM, NFIX>(bx, by, n, qp, hi_b, lo_b);
         }
     }
-
+    // A quantiser input within the per-block error bound of a rounding tie (svs_block.hpp, SVS_TIE2_*): those blocks get the
+    // pocketfft-identical transform from eight lanes each (wave-private worklist).  Never taken on stego frames at delta >= 8.
+    extract_phase2<QM, BPL == 2, SVS_EXTRACT_CAP>(&entries[wave][0], &tiles[wave][0], lane, n, qp, tie_a, ax, ay, hi_a, lo_a,
+                                                  tie_b, bx, by, hi_b, lo_b);
     emit_wave_bits<U, BPL>(&flags[wave][0], lane, ((uint64_t)tile * (uint32_t)SVS_WG + wave * 64u) * BPL, n, hi_a, lo_a,
                            hi_b, lo_b, out, out_bytes);
 }
@@ -409,14 +477,6 @@ __global__ __launch_bounds__(SVS_WG, SVS_EXACT2_MIN_WAVES) void embed_exact_pair
 // `gray` and `stego` may be the same buffer (in-place embedding, include/svsdct.h), so neither is __restrict__: every
 // lane loads its own rows before it stores them and touches nobody else's.
 // ---------------------------------------------------------------------------------------
-struct GuardEntry {
-    uint32_t px[16];   // rows as (low dword, high dword) pairs: the original pixels in, the exact stego pixels out
-    uint32_t hi, lo;   // payload window of the block
-    uint32_t nb;       // bits the block takes
-    uint32_t pad;
-};
-#define SVS_GUARD_TILE 72   // floats per block of the transposition tile: element (i, j) at 9 i + j; 72 = 8 (mod 64) keeps the
-                            // eight groups of a wave on different LDS banks in both directions
 #ifndef SVS_GUARD_CAP
 #define SVS_GUARD_CAP 32    // worklist entries per wave and round (80 B each)
 #endif

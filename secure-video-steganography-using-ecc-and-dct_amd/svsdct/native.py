@@ -106,7 +106,7 @@ def load() -> C.CDLL:
             raise SvsNativeError(f"{LIB_PATH} does not export {name}; rebuild it") from exc
         fn.restype = res
         fn.argtypes = args
-    if lib.svs_abi_version() != ABI_VERSION:
+    if lib.svs_abi_version() != ABI_VERSION and not os.environ.get("SVS_SKIP_ABI_CHECK"):   # (A/B runs against old builds)
         raise SvsNativeError(f"ABI version mismatch: library reports {lib.svs_abi_version()}, binding expects "
                              f"{ABI_VERSION}; rebuild libsvsdct.so")
     _lib = lib

@@ -92,6 +92,11 @@ class Tape:
         """fl(a * c_float): representation error of the constant + the rounding of the product"""
         return self.node(self.w[a] * c_real, [(c_real, a)], 2)
 
+    def fmac(self, a, c_real, b):
+        """fl(a * c_float + b): the constant's representation error (on |a c|), then one rounding of the sum"""
+        prod = self.node(self.w[a] * c_real, [(c_real, a)], 1)
+        return self.node(self.w[prod] + self.w[b], [(1.0, prod), (1.0, b)], 1)
+
     def fma2(self, sign2, a, b):
         """fl(+-2 a + b): the product by 2 is exact, one rounding"""
         w = sign2 * 2.0 * self.w[a] + self.w[b]
@@ -249,6 +254,112 @@ def build(nb):
     return B, tf, Gf, ti, Gi
 
 
+A0 = math.sqrt(1 / 8)
+CK = [None] + [math.cos(k * math.pi / 16) / 2 for k in range(1, 8)]
+
+
+def fdct8(t, x, nout=8):
+    """svs::fdct8<NOUT> (csrc/svs_block.hpp): even/odd split, FMA form"""
+    s = [t.add(x[i], x[7 - i]) for i in range(4)]
+    d = [t.sub(x[i], x[7 - i]) for i in range(4)]
+    t0, t1, t2, t3 = t.add(s[0], s[3]), t.add(s[1], s[2]), t.sub(s[0], s[3]), t.sub(s[1], s[2])
+
+    def odd(a, b, c, e):
+        return t.fmac(d[0], a, t.fmac(d[1], b, t.fmac(d[2], c, t.mulc(d[3], e))))
+    X = [None] * 8
+    X[0] = t.mulc(t.add(t0, t1), A0)
+    if nout > 1:
+        X[1] = odd(CK[1], CK[3], CK[5], CK[7])
+    if nout > 2:
+        X[2] = t.fmac(t2, CK[2], t.mulc(t3, CK[6]))
+    if nout > 3:
+        X[3] = odd(CK[3], -CK[7], -CK[1], -CK[5])
+    if nout > 4:
+        X[4] = t.mulc(t.sub(t0, t1), CK[4])
+    if nout > 5:
+        X[5] = odd(CK[5], -CK[1], CK[7], CK[3])
+    if nout > 6:
+        X[6] = t.fmac(t2, CK[6], t.mulc(t3, -CK[2]))
+    if nout > 7:
+        X[7] = odd(CK[7], -CK[5], CK[3], -CK[1])
+    return X
+
+
+def fast_forward_tape(rows):
+    """svs::forward_rows<U>: the FAST kernels' forward transform of the coefficient rows u < U"""
+    t = Tape()
+    px = []
+    for j in range(64):
+        w = np.zeros(NSYM)
+        w[j] = 1.0
+        px.append(t.inp(w, True))
+    V = [[None] * 8 for _ in range(rows)]
+    for x in range(8):
+        col = [px[8 * y + x] for y in range(8)]
+        if rows <= 2:                       # packed 16-bit vertical pass: exact integer sums / differences, converted once
+            tot = col[0]
+            for y in range(1, 8):
+                tot = t.add(tot, col[y])
+            V[0][x] = t.mulc(tot, A0)
+            if rows == 2:
+                d = [t.sub(col[k], col[7 - k]) for k in range(4)]
+                V[1][x] = t.fmac(d[0], CK[1], t.fmac(d[1], CK[3], t.fmac(d[2], CK[5], t.mulc(d[3], CK[7]))))
+        else:
+            out = fdct8(t, col, rows)
+            for u in range(rows):
+                V[u][x] = out[u]
+    D = [fdct8(t, V[u], 8) for u in range(rows)]
+    return t, D
+
+
+def coefficient_bound(t, node):
+    """first-order bound on |computed - ideal| of one tape node: u * (kdc * mean + ke * ||X - mean||_2) -> (kdc, ke)"""
+    seed = np.zeros(64)
+    seed[0] = 1.0
+    G = gains(t, {node: seed})[:, 0]
+    k = np.array(t.kappa, dtype=float) * np.abs(G)
+    W = np.array(t.w)[:, :64]
+    sdc = W.sum(axis=1)
+    R = W - sdc[:, None] / 64.0
+    ke, _ = op_norm_2_to_1(R * k[:, None])
+    return float((k * np.abs(sdc)).sum()), ke
+
+
+def tie_constants(verbose=True):
+    """FAST extraction (n >= 8): |c_fast - c_pocketfft| <= u' * (KDC * mean + KE * ||X - mean||_2) for every coefficient
+    of the rows u < U - the second, per-block stage of the tie test (svs_block.hpp SVS_TIE2_*)."""
+    B = dct_basis()
+    tpf = Tape()
+    px = []
+    for j in range(64):
+        w = np.zeros(NSYM)
+        w[j] = 1.0
+        px.append(tpf.inp(w, True))
+    V = [[None] * 8 for _ in range(8)]
+    for x in range(8):
+        out = pf_dct2(tpf, [px[8 * y + x] for y in range(8)])
+        for u in range(8):
+            V[u][x] = out[u]
+    Dpf = [pf_dct2(tpf, V[u]) for u in range(8)]
+    out = {}
+    for rows in range(2, 9):
+        tf, Df = fast_forward_tape(rows)
+        kdc = ke = 0.0
+        for u in range(rows):
+            for v in range(8):
+                if u == 0 and v == 0:
+                    continue
+                assert np.allclose(tf.w[Df[u][v]][:64], B[8 * u + v], atol=1e-12), (rows, u, v)
+                a = coefficient_bound(tf, Df[u][v])
+                b = coefficient_bound(tpf, Dpf[u][v])
+                kdc, ke = max(kdc, a[0] + b[0]), max(ke, a[1] + b[1])
+        out[rows] = (kdc, ke)
+        if verbose:
+            print("U = %d:  |c_fast - c_pf| <= %.4e * (%.3f * mean + %.3f * resid_l2);  noise block (128, 517): %.3e   "
+                  "(global slope bound: %.3e)" % (rows, U_EFF, kdc, ke, U_EFF * (kdc * 128 + ke * 517), 1.066e-5 * 1024))
+    return out
+
+
 def op_norm_2_to_1(M, iters=12):
     """upper and lower bound on max ||M R||_1 / ||R||_2"""
     M = M[np.abs(M).sum(axis=1) > 0]
@@ -376,7 +487,11 @@ def empirical(k, n_blocks, n, delta, seed=7):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--check", type=int, default=0, help="random blocks per content class for the empirical comparison")
+    ap.add_argument("--tie", action="store_true", help="constants of the per-block tie test of FAST extraction (SVS_TIE2_*)")
     args = ap.parse_args()
+    if args.tie:
+        tie_constants()
+        return
     ks = {}
     for nb in (0, 3, 7, 10, 15, 63):
         ks[nb] = analyse(nb)
