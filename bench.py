@@ -38,7 +38,15 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--frames", type=int, default=600, help="frames per GPU per step")
+    ap.add_argument("--frames", type=int, default=600, help="frames per GPU per step (weak scaling: every rank runs this batch)")
+    ap.add_argument("--total-frames", type=int, default=0,
+                    help="strong scaling: frames of the WHOLE job, divided over the ranks by svsdct.batch.shard_frames "
+                         "(contiguous ranges, rank order = stream order); overrides --frames, e.g. --total-frames 2400 "
+                         "--height 1080 --width 1920 --n-ac 10 for BASELINE configs[3], --total-frames 1200 --height 4320 "
+                         "--width 7680 for configs[4]")
+    ap.add_argument("--mode", default=None, choices=["fast", "guarded", "exact"],
+                    help="transform mode of the timed embed / extract (default: fast, the device-level default; at "
+                         "n_ac <= 7 fast and guarded are the same launch and bit-identical to the reference)")
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--width", type=int, default=3840)
     ap.add_argument("--n-ac", type=int, default=3)
@@ -85,6 +93,18 @@ def _cpu_worker(task):
     return time.perf_counter() - t0, int((got != bits).sum())
 
 
+def kernel_source_sha() -> str:
+    """sha256 over the kernel sources (csrc/*.hpp, *.hip, include/*.h): ties a committed counter capture to a build"""
+    import hashlib
+    h = hashlib.sha256()
+    for d, pat in ((os.path.join(PKG_DIR, "csrc"), (".hpp", ".hip")), (os.path.join(REPO, "include"), (".h",))):
+        for name in sorted(os.listdir(d)):
+            if name.endswith(pat):
+                with open(os.path.join(d, name), "rb") as fh:
+                    h.update(name.encode() + b"\0" + fh.read())
+    return h.hexdigest()
+
+
 def usable_cpus() -> int:
     """CPUs this process may actually use: scheduler affinity, further limited by a cgroup CPU quota if one is set
     (a GPU box hands each job a share of the host, not the 256 logical cores os.cpu_count() reports)."""
@@ -129,6 +149,12 @@ def cpu_baseline_all_cores(args):
 def main():
     args = parse_args()
     if "RANK" not in os.environ and (args.gpus > 1 or args.force_dist):
+        # a profiler's preloaded library has initialised the GPU before this process started; starting the ranks from such
+        # a process is the exec-after-GPU-init hop the pool forbids.  Counter passes are single-rank (tools/gpu_pmc.sh).
+        if os.environ.get("ROCP_TOOL_LIBRARIES") or "rocprof" in os.environ.get("LD_PRELOAD", ""):
+            raise SystemExit("bench.py: refusing to start ranks from a process running under rocprofv3; profile one rank "
+                             "(python bench.py, no --gpus / --force-dist) or launch the ranks with torch.distributed.run "
+                             "under the profiler yourself")
         raise SystemExit(launch_ranks(args))             # parent of the ranks: never initialises the GPU
     cpu_parallel = None
     if args.cpu_frames > 0 and int(os.environ.get("WORLD_SIZE", "1")) == 1:
@@ -164,7 +190,14 @@ def main():
     lib = native.load()                      # raises if the HIP library is missing - no fallback
     native.ensure_device(local_rank)
 
-    F, H, W, n_ac, delta = args.frames, args.height, args.width, args.n_ac, args.delta
+    H, W, n_ac, delta = args.height, args.width, args.n_ac, args.delta
+    if args.total_frames > 0:        # strong scaling: this rank's contiguous share of the clip
+        first_frame, F = batch.shard_frames(args.total_frames, world, rank)
+        if F == 0:
+            raise SystemExit(f"--total-frames {args.total_frames} leaves rank {rank} of {world} without frames")
+    else:                            # weak scaling: every rank runs the N = 1 batch on its own frames
+        first_frame, F = rank * args.frames, args.frames
+    mode = args.mode or os.environ.get("SVS_DCT_MODE") or "fast"
     planes = Planes.contiguous(F, H, W)
     cap = batch.capacity_bits(F, H, W, n_ac)
     nbytes = (cap + 7) // 8
@@ -173,18 +206,26 @@ def main():
     gray = torch.empty((F, H, W), dtype=torch.uint8, device=dev)
     stego = torch.empty_like(gray)
     payload = torch.zeros(nbytes + 8 - nbytes % 4, dtype=torch.uint8, device=dev)
+    per_frame_bits = batch.capacity_bits(1, H, W, n_ac)
+    first_bit = first_frame * per_frame_bits                 # this rank's offset in the job's bit stream
+    # dist.gather wants equal sizes: every rank contributes the packed bits of the LARGEST share (ranks differ by at most one
+    # frame under --total-frames; the tail of a smaller share is padding the check below ignores)
+    shares = [batch.shard_frames(args.total_frames, world, r) for r in range(world)] if args.total_frames > 0 else \
+             [(r * args.frames, args.frames) for r in range(world)]
+    gather_bytes = (max(c for _, c in shares) * per_frame_bits + 7) // 8
     # extracted bits are double-buffered so that the gather of step k overlaps the kernels of step k+1
-    ext_bufs = [torch.zeros(nbytes + 8 - nbytes % 4, dtype=torch.uint8, device=dev) for _ in range(2 if use_dist else 1)]
-    first_frame = rank * F
+    ext_len = max(nbytes, gather_bytes)
+    ext_bufs = [torch.zeros(ext_len + 8 - ext_len % 4, dtype=torch.uint8, device=dev) for _ in range(2 if use_dist else 1)]
     native.check(lib.svs_fill_synthetic_dev(gray.data_ptr(), C.byref(planes), SEED, first_frame, 16, 224, stream),
                  "fill_synthetic")
-    native.check(lib.svs_fill_bits_dev(payload.data_ptr(), cap, SEED, rank * cap, stream), "fill_bits")
+    native.check(lib.svs_fill_bits_dev(payload.data_ptr(), cap, SEED, first_bit, stream), "fill_bits")
     gathered = [None, None]
     if use_dist and rank == 0:
-        gathered = [[torch.empty(nbytes, dtype=torch.uint8, device=cdev) for _ in range(world)] for _ in range(2)]
+        gathered = [[torch.empty(gather_bytes, dtype=torch.uint8, device=cdev) for _ in range(world)] for _ in range(2)]
     pending = [None, None]
     torch.cuda.synchronize()
     step_no = [0]
+    gather_wait = [0.0]       # host seconds this rank spent blocked on a gather's completion
 
     def step(ev=None):
         slot = step_no[0] % len(ext_bufs)
@@ -193,30 +234,34 @@ def main():
         if ev:
             ev[0].record()
         used = batch.embed_device(gray.data_ptr(), stego.data_ptr(), planes, delta, n_ac, payload.data_ptr(), 0, cap,
-                                  stream)
+                                  stream, mode=mode)
         if ev:
             ev[1].record()
         if pending[slot] is not None:
+            tw = time.perf_counter()
             pending[slot].wait()          # the gather that last read this buffer must have finished
+            gather_wait[0] += time.perf_counter() - tw
             pending[slot] = None
         got = batch.extract_device(stego.data_ptr(), planes, delta, n_ac, extracted.data_ptr(), extracted.numel(),
-                                   stream)
+                                   stream, mode=mode)
         if ev:
             ev[2].record()
         if use_dist:
             # the path's one collective (RCCL over xGMI): packed bits of every rank to rank 0, in rank order;
             # asynchronous, so it runs beside the next step's kernels
             if args.rehearse_gloo:
-                sdist.gather_packed(extracted.cpu(), nbytes, dst=0, recv=gathered[slot])
+                sdist.gather_packed(extracted.cpu(), gather_bytes, dst=0, recv=gathered[slot])
             else:
-                pending[slot] = dist.gather(extracted[:nbytes], gathered[slot] if rank == 0 else None, dst=0,
+                pending[slot] = dist.gather(extracted[:gather_bytes], gathered[slot] if rank == 0 else None, dst=0,
                                             async_op=True)
         return used, got
 
     def drain():
         for i, w in enumerate(pending):
             if w is not None:
+                tw = time.perf_counter()
                 w.wait()
+                gather_wait[0] += time.perf_counter() - tw
                 pending[i] = None
 
     used = got = cap
@@ -230,6 +275,7 @@ def main():
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
+    gather_wait[0] = 0.0
     t0 = time.perf_counter()
     for k in range(args.steps):
         step(events[k])
@@ -246,6 +292,12 @@ def main():
 
     embed_ms = sum(e[0].elapsed_time(e[1]) for e in events) / args.steps
     extract_ms = sum(e[1].elapsed_time(e[2]) for e in events) / args.steps
+    per_rank = [[embed_ms, extract_ms, gather_wait[0] / args.steps * 1e3]]
+    if use_dist:        # every rank's kernel times on rank 0: the SCALE record can show imbalance between GPUs
+        mine = torch.tensor(per_rank[0], dtype=torch.float64, device=cdev)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = [[float(x) for x in t.tolist()] for t in allr]
 
     # ---- correctness of what was just timed (outside the timed region) -------------------------
     cnt = torch.zeros(1, dtype=torch.int64, device=dev)
@@ -268,21 +320,21 @@ def main():
     if use_dist and rank == 0:
         # the gathered stream on rank 0: slice r must be rank r's payload (regenerated here from the counter-based
         # generator), i.e. the reassembled global bit stream is correct and in rank order
-        expect = torch.zeros_like(payload)
+        expect = torch.zeros(gather_bytes + 8 - gather_bytes % 4, dtype=torch.uint8, device=dev)
+        padded = torch.zeros_like(expect)
         wrong = 0
-        for r in range(world):
-            native.check(lib.svs_fill_bits_dev(expect.data_ptr(), cap, SEED, r * cap, stream), "fill_bits")
-            piece = gathered[last][r].to(dev)
-            padded = torch.zeros_like(payload)
-            padded[:nbytes] = piece
-            native.check(lib.svs_bit_errors_dev(padded.data_ptr(), expect.data_ptr(), cap, cnt.data_ptr(), stream), "ber")
+        for r, (first_r, count_r) in enumerate(shares):
+            bits_r = count_r * per_frame_bits
+            native.check(lib.svs_fill_bits_dev(expect.data_ptr(), bits_r, SEED, first_r * per_frame_bits, stream), "fill_bits")
+            padded[:gather_bytes] = gathered[last][r].to(dev)
+            native.check(lib.svs_bit_errors_dev(padded.data_ptr(), expect.data_ptr(), bits_r, cnt.data_ptr(), stream), "ber")
             torch.cuda.synchronize()
             wrong += int(cnt.item())
-        gather_ok = bool(wrong == 0 and torch.equal(gathered[last][0].to(dev), extracted[:nbytes]))
+        gather_ok = bool(wrong == 0 and torch.equal(gathered[last][0].to(dev)[:nbytes], extracted[:nbytes]))
 
     result = None
     if rank == 0:
-        pixels_per_step = world * F * H * W
+        pixels_per_step = sum(c for _, c in shares) * H * W
         mpix_s = pixels_per_step * args.steps / elapsed / 1e6
         embed_bytes = F * H * W * 2 + nbytes            # read u8 + write u8 + packed payload
         extract_bytes = F * H * W + nbytes
@@ -295,28 +347,51 @@ def main():
             try:
                 with open(tpath) as fh:
                     tj = json.load(fh)
-                if tj.get("frames") == F and tj.get("height") == H and tj.get("width") == W and tj.get("n_ac", 3) == n_ac:
+                same_workload = (tj.get("frames") == F and tj.get("height") == H and tj.get("width") == W and
+                                 tj.get("n_ac", 3) == n_ac)
+                same_kernels = tj.get("kernel_source_sha256") == kernel_source_sha()
+                if same_workload and same_kernels:
                     traffic = tj.get("embed_bytes_per_launch")
                     traffic_source = {"file": "profiles/hbm_traffic.json", "captured": tj.get("captured"),
                                       "how": "rocprofv3 --pmc passes of this bench command (tools/gpu_pmc.sh), "
-                                             "2 x FETCH_SIZE + WRITE_SIZE per embed launch; not measured in this run"}
+                                             "2 x FETCH_SIZE + WRITE_SIZE per embed launch; not measured in this run; the "
+                                             "capture's kernel sources (sha256 of csrc/ + include/) are this build's"}
+                elif same_workload:
+                    traffic_source = {"file": "profiles/hbm_traffic.json", "captured": tj.get("captured"),
+                                      "how": "STALE: captured from other kernel sources than this build's - traffic "
+                                             "reported as null; re-run tools/gpu_pmc.sh + tools/pmc_summary.py"}
             except Exception:
                 traffic, traffic_source = None, None
         result = {
             "metric": "Mpixels/sec embed+extract round-trip at 4K; payload bit-error rate (must be 0)",
             "value": mpix_s, "unit": "Mpix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "strong" if args.total_frames > 0 else "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic" + (" (gloo rehearsal - not a result)" if args.rehearse_gloo else ""),
-            "config": {"workload": f"{W}x{H} x {F} frames per GPU, {n_ac} AC coeffs/block, delta={delta:g}, "
-                                   f"full-capacity payload ({cap} bits per GPU), gray planes resident in HBM",
-                       "frames_per_gpu": F, "height": H, "width": W, "n_ac": n_ac, "delta": delta,
+            "config": {"workload": (f"{W}x{H} x {args.total_frames} frames divided over {world} GPU(s)" if args.total_frames > 0
+                                    else f"{W}x{H} x {F} frames per GPU") +
+                                   f", {n_ac} AC coeffs/block, delta={delta:g}, full-capacity payload "
+                                   f"({per_frame_bits} bits per frame), gray planes resident in HBM",
+                       "frames_per_gpu": [c for _, c in shares] if args.total_frames > 0 else F,
+                       "total_frames": sum(c for _, c in shares), "height": H, "width": W, "n_ac": n_ac, "delta": delta,
+                       "mode": mode + (" (n_ac <= 7: the same launch as guarded - stego pixels bit-identical to the reference)"
+                                       if mode == "fast" and n_ac <= 7 else ""),
                        "sharding": "frames" if world > 1 else "none",
                        "collective": ("gloo gather of packed bits through host memory (rehearsal)" if args.rehearse_gloo else
                                       "rccl gather of packed bits") if use_dist else "none"},
-            "payload_bit_errors": bit_errors, "payload_ber": bit_errors / (cap * world),
+            "payload_bit_errors": bit_errors, "payload_ber": bit_errors / (sum(c for _, c in shares) * per_frame_bits),
             "psnr_frame0_db": psnr0,
-            "kernel_ms": {"embed": embed_ms, "extract": extract_ms},
-            "roofline": {"bound": "hbm", "kernel": "embed_kernel (+ embed_replay_kernel: the events bracket both launches of the FAST embed)",
+            "kernel_ms": {"embed": embed_ms, "extract": extract_ms,
+                          "per_rank": {"embed_min": min(r[0] for r in per_rank), "embed_max": max(r[0] for r in per_rank),
+                                       "extract_min": min(r[1] for r in per_rank), "extract_max": max(r[1] for r in per_rank),
+                                       "embed": [r[0] for r in per_rank], "extract": [r[1] for r in per_rank]}},
+            "gather": ({"bytes_received_by_rank0_per_step": world * gather_bytes,
+                        "host_wait_ms_per_step_rank0": per_rank[0][2],
+                        "host_wait_ms_per_step_max_over_ranks": max(r[2] for r in per_rank),
+                        "note": "asynchronous: the gather of step k runs beside the kernels of step k + 1; the wait is what "
+                                "is left when its buffer is needed again (and at the end of the timed region)"}
+                       if use_dist else None),
+            "roofline": {"bound": "hbm", "kernel": "embed_kernel (one launch: cheap arithmetic + in-kernel exact replay of undecided blocks)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "algorithmic_bytes_per_launch": embed_bytes,

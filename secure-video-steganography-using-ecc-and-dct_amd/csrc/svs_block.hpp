@@ -178,12 +178,16 @@ SVS_HD uint32_t put_pixel_rne(float v, uint32_t old) {
 // wave's FP32 rounding mode switched to round-toward-zero for exactly these eight instructions: the conversion saturates
 // to [0, 255] and follows MODE.fp_round (measured on gfx950 with tools/probes/cvt_round_mode.hip: 126.99999 -> 126,
 // 0.99999994 -> 0, -0.9 -> 0, 255.7 -> 255), which saves the v_floor_f32 per pixel of the floor-then-convert form.  One asm
-// statement, so that no other floating-point instruction can be scheduled into the window.
+// statement, so that no other floating-point instruction can be scheduled into the window.  It opens with s_nop 1: two of
+// these statements can end up back to back, and s_setreg -> s_setreg on the same hardware register needs 2 wait states that
+// the compiler's hazard recogniser cannot insert inside inline asm.  The kernels run with the default
+// round-to-nearest-even mode, which the closing s_setreg restores.
 SVS_HD void store_row_trunc(float p0, float p1, float p2, float p3, float p4, float p5, float p6, float p7, uint32_t &lo4,
                             uint32_t &hi4) {
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(SVS_NO_CVT_PK_U8) && !defined(SVS_NO_RTZ_STORE)
     uint32_t a, b;
     asm volatile(
+        "s_nop 1\n\t"
         "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 3\n\t"
         "s_nop 0\n\t"
         "v_cvt_pk_u8_f32 %0, %2, 0, 0\n\t"
@@ -440,7 +444,7 @@ SVS_HD float fmin3_abs(float a, float b, float c) { return fminf(a, fminf(fabsf(
 // into the integer k, and a coefficient that vanishes by exact cancellation of the pixels comes out of this function's
 // forward transform as a 1e-5 residue whose "change" of -1e-5 floors a whole block one level down.
 // Two levels, so that ordinary content pays two operations per coefficient:
-//   1. a block is GENERIC when some applied coefficient k (other than 4, 32, 36) has both |c_k| and |change_k| above
+//   1. a block is GENERIC when some applied coefficient k <= 16 (other than 4) has both |c_k| and |change_k| above
 //      SVS_FAST_GENERIC = 2^-5 (above any residue: |c_fast - c_exact| <= 1.07e-5 c00 <= 0.022, SVS_TIE_SLOPE).  Its change
 //      is then a continuous function of the pixels (c_k's distance from the quantiser grid), so a predicted value on the
 //      integer grid is an isolated coincidence (2e-4 of the pixels lie within the reference's noise of it), not structure.
@@ -450,6 +454,7 @@ SVS_HD float fmin3_abs(float a, float b, float c) { return fminf(a, fminf(fabsf(
 // transform (both unbiased: PSNR unaffected); GUARDED / EXACT modes do.
 #define SVS_FAST_GUARD 0x1p-13f
 #define SVS_FAST_GENERIC 0x1p-5f
+#define SVS_FAST_GENERIC_SPAN 16   // coefficients 1..16 are looked at for level 1 (a block none of them makes generic is scanned)
 template <int U, int QM, int NFIX = 0>
 SVS_HD bool embed_block(uint32_t (&rx)[8], uint32_t (&ry)[8], uint32_t n_rt, uint32_t nb, uint32_t hi, uint32_t lo,
                         const QimParams &qp) {
@@ -476,7 +481,7 @@ SVS_HD bool embed_block(uint32_t (&rx)[8], uint32_t (&ry)[8], uint32_t n_rt, uin
             if constexpr (QM == QM_DOUBLE) cn = (float)((double)q * qp.delta_d);
             else cn = (float)q * qp.delta_f;
             change = ((uint32_t)i < nb) ? cn - c : 0.0f;
-            if (k != 4 && k != 32 && k != 36) generic = fmaxf(generic, fminf(fabsf(c), fabsf(change)));
+            if (k != 4 && k <= SVS_FAST_GENERIC_SPAN) generic = fmaxf(generic, fminf(fabsf(c), fabsf(change)));
         }
         D[u][v] = change;
     }

@@ -449,6 +449,9 @@ int svs_embed_dev(const uint8_t *d_gray, uint8_t *d_stego, const svs_planes *pla
     // Outside the delta range the guard is useless (every block undecided below, BETA > 1/8 above): exact kernels.
     const bool in_range = delta >= SVS_GUARD_DELTA_MIN && delta <= SVS_GUARD_DELTA_MAX;
     bool streaming = use > 0 && in_range && !(flags & SVS_EXACT_POCKETFFT) && (rows == 1 || !(flags & SVS_EXACT_GUARDED));
+    // (the streaming kernel stays ahead of the lane-per-block pocketfft kernel up to all eight coefficient rows: 1.20 vs
+    // 1.33 ms per 200 x 4K frames at n = 63, profiles/r03_many_coefficients.txt; SVS_FAST_MAX_ROWS is the A/B knob)
+    if (rows > (int)env_chunk("SVS_FAST_MAX_ROWS", 8)) streaming = false;
     if ((flags & SVS_EXACT_GUARDED) && env_chunk("SVS_GUARDED_OFF", 0) != 0) streaming = false;   // A/B knob
     // SVS_EXACT_BPL=2 (experiment knob): exact arithmetic on two adjacent blocks per lane with every transform instruction
     // packed over the pair (embed_exact_pair_kernel).  Measured SLOWER than the one-block kernel (3.54 vs 3.16 ms at n = 3,
@@ -724,7 +727,8 @@ int svs_embed_bgr_dev(const uint8_t *d_bgr_in, int64_t in_row_pitch, int64_t in_
     // payload cannot be embedded (every block is then round-tripped, which only the exact arithmetic reproduces)
     const int rows_n = rows_for(n);
     const bool in_range = delta >= SVS_GUARD_DELTA_MIN && delta <= SVS_GUARD_DELTA_MAX;
-    const bool streaming = use > 0 && in_range && !(flags & SVS_EXACT_POCKETFFT) && (rows_n == 1 || !(flags & SVS_EXACT_GUARDED));
+    const bool streaming = use > 0 && in_range && !(flags & SVS_EXACT_POCKETFFT) && (rows_n == 1 || !(flags & SVS_EXACT_GUARDED)) &&
+                           rows_n <= (int)env_chunk("SVS_FAST_MAX_ROWS", 8);
     const bool exact = !streaming && (use > 0 || n_bits > 0);
     svs::QimParams qp;
     const int qm = make_qim(use == 0 ? 1.0 : delta, &qp);

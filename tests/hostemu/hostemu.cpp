@@ -128,7 +128,7 @@ uint64_t emu_embed(const uint8_t *gray, uint8_t *stego, int F, int H, int W, dou
     const bool guarded = (exact == 4 || exact == 0) && use > 0 && svs::rows_for(n) == 1 && in_range;
     if (guarded) svs::make_guard(delta, 1, &qp);
     if (exact == 4 && !guarded) exact = 1;
-    if (exact == 0 && !in_range) exact = 1;
+    if (exact == 0 && !in_range) exact = 1;   // svs_embed_dev: out-of-range delta
     if (use == 0) {
         if (n_bits > 0) {  // nothing consumed -> every block entered and round-tripped (either mode: svs_embed_dev)
             for (uint64_t gb = 0; gb < total; ++gb) {

@@ -11,8 +11,10 @@ Corrections applied, as MI355X_MICROARCH.md (HBM section) prescribes:
 """
 import collections, csv, glob, json, os, sys
 repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, repo)
+from bench import kernel_source_sha      # what bench.py compares the capture against
 src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(repo, "gpurun_out")
-tag = sys.argv[2] if len(sys.argv) > 2 else "r01"
+tag = sys.argv[2] if len(sys.argv) > 2 else "r03"
 F, H, W, n = 600, 2160, 3840, 3
 agg = collections.defaultdict(list)
 for f in glob.glob(os.path.join(src, "pmc_*", "*", "*_counter_collection.csv")):
@@ -43,12 +45,6 @@ for kern, alg in kerns:
         "SQ_INSTS_VALU_per_wave": mean.get((kern, "SQ_INSTS_VALU"), 0) / max(mean.get((kern, "SQ_WAVES"), 1), 1),
         "effective_clock_GHz_note": "GRBM_GUI_ACTIVE/8/kernel time; see raw counters",
         "raw_means": {c: v for (k, c), v in mean.items() if k == kern}}
-# the FAST embed is two launches since round 2: embed_kernel + embed_replay_kernel (reads the replay map)
-replay = 0.0
-if ("embed_replay_kernel", "FETCH_SIZE") in mean:
-    replay = mean[("embed_replay_kernel", "FETCH_SIZE")] * 1024 * 2.0 + mean.get(("embed_replay_kernel", "WRITE_SIZE"), 0.0) * 1024
-    out["kernels"]["embed_replay_kernel"] = {"hbm_bytes_per_launch": replay,
-                                             "raw_means": {c: v for (k, c), v in mean.items() if k == "embed_replay_kernel"}}
 import subprocess, datetime
 try:
     rev = subprocess.run(["git", "-C", repo, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
@@ -60,8 +56,8 @@ with open(os.path.join(repo, "profiles", f"{tag}_pmc_summary.json"), "w") as fh:
     json.dump(out, fh, indent=1, sort_keys=True)
 with open(os.path.join(repo, "profiles", "hbm_traffic.json"), "w") as fh:
     json.dump({"frames": F, "height": H, "width": W, "n_ac": n,
-               "embed_bytes_per_launch": out["kernels"]["embed_kernel"]["hbm_bytes_per_launch"] + replay,
-               "embed_replay_pass_bytes": replay, "captured": captured,
+               "embed_bytes_per_launch": out["kernels"]["embed_kernel"]["hbm_bytes_per_launch"],
+               "captured": captured, "kernel_source_sha256": kernel_source_sha(),
                "extract_bytes_per_launch": out["kernels"][extract_name]["hbm_bytes_per_launch"],
                "source": f"profiles/{tag}_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, tools/gpu_pmc.sh)"},
               fh, indent=1)
