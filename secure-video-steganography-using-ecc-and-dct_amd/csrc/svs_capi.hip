@@ -140,10 +140,12 @@ Tuning extract_tuning(int rows, const svs_planes *p, const void *a) {
     return t;
 }
 
-// default caps (workgroups of 256 threads per CU; 0 = whatever the registers allow).  Only the one-row embed kernels gain
-// (+5..6 % at 5 instead of the 8 their registers allow, with one or two blocks per lane); every extract kernel, the embed
-// kernels with more rows, the exact kernels and a plain copy are fastest uncapped (tools/occupancy_sweep.sh).
-uint32_t embed_wg_per_cu(int rows, int bpl) { (void)bpl; return rows == 1 ? 5u : 0u; }
+// default caps (workgroups of 256 threads per CU; 0 = whatever registers and LDS allow).  Round 3: none.  The one-row embed
+// kernel with two blocks per lane is register-limited to 4 workgroups per CU (100 VGPRs) and insensitive to anything above
+// (sweep 4..8: 1.637-1.648 ms); with one block per lane (odd block counts per row) it is fastest uncapped (8: 1.80 ms, 7: 1.83,
+// 6: 1.92, 5: 2.20; profiles/r03_ab_occupancy.txt).  Every extract kernel, the embed kernels with more rows, the exact kernels
+// and a plain copy have always been fastest uncapped (tools/occupancy_sweep.sh).
+uint32_t embed_wg_per_cu(int rows, int bpl) { (void)rows; (void)bpl; return 0u; }
 uint32_t extract_wg_per_cu(int rows) { (void)rows; return 0; }
 
 unsigned long long *g_guard_counter = nullptr;   // measurement hook (svs_guard_counter_set): blocks redone exactly
