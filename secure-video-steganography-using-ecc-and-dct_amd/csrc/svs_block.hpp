@@ -271,11 +271,31 @@ SVS_HD void vertical_u1_packed(const uint32_t (&w)[8], float (&v0)[4]) {
     }
 }
 
-// `v0` (optional): receives row 0 of the vertical pass, V[0][x] = fl(colsum_x * a(0)) - the one part of this transform that
-// is bit-identical to pocketfft's (its sums are exact integers and the product rounds once), from which
-// pf_row0_coefficient4 below derives the reference's own value of flat index 4.
+// Flat index 4 (coefficient (0, 4), basis +-1/8) exactly as pocketfft computes it, from row 0 of the vertical pass (which is
+// pocketfft's, see forward_rows): for integer pixels this coefficient is a multiple of 1/8, so c / delta sits EXACTLY on a
+// rounding tie in 1 of 8 delta blocks (SURVEY N6) and only the reference's own float32 sequence says which way it falls.
+// These are the operations of svs::pf::dct2_8 that feed output 4 (radb2 / radb4 sums, one twiddle product), nine in all.
+SVS_HD float pf_row0_coefficient4(const float *v0) {
+    const float c0 = 2.0f * v0[0], c7 = 2.0f * v0[7];
+    const float c1 = v0[1] + v0[2], c3 = v0[3] + v0[4], c5 = v0[5] + v0[6];
+    const float h0 = c0 + c7, h1 = c1 + c5;
+    const float a0 = fmaf(2.0f, c3, h0);
+    return fmaf(-2.0f, h1, a0) * 0x1.6a09e6p-3f;   // r[4] * (float(cos(pi/4)) / 4)
+}
+
+// `side` (optional): two by-products of row 0 of the vertical pass, V[0][x] = fl(colsum_x * a(0)) - the one part of this
+// transform that is bit-identical to pocketfft's (its sums are exact integers and the product rounds once): the reference's
+// own value of flat index 4 (pf_row0_coefficient4) and the sum of V[0] (= a(0) * the block's pixel sum, up to 8 roundings).
+// Taken here so that the eight values need not stay in registers.
+struct ForwardSide {
+    float c4, v0_sum;
+};
+SVS_HD void forward_side(const float (&v0)[8], ForwardSide *side) {
+    side->c4 = pf_row0_coefficient4(v0);
+    side->v0_sum = ((v0[0] + v0[1]) + (v0[2] + v0[3])) + ((v0[4] + v0[5]) + (v0[6] + v0[7]));
+}
 template <int U>
-SVS_HD void forward_rows(const uint32_t (&rx)[8], const uint32_t (&ry)[8], float (&D)[U][8], float *v0 = nullptr) {
+SVS_HD void forward_rows(const uint32_t (&rx)[8], const uint32_t (&ry)[8], float (&D)[U][8], ForwardSide *side = nullptr) {
     float V[U][8];
     if constexpr (U == 1 && SVS_PACKED_VERTICAL_U1) {
         float a0[4], b0[4];
@@ -283,7 +303,7 @@ SVS_HD void forward_rows(const uint32_t (&rx)[8], const uint32_t (&ry)[8], float
         vertical_u1_packed(ry, b0);
 #pragma unroll
         for (int x = 0; x < 4; ++x) { V[0][x] = a0[x]; V[0][4 + x] = b0[x]; }
-        if (v0) { _Pragma("unroll") for (int x = 0; x < 8; ++x) v0[x] = V[0][x]; }
+        if (side) forward_side(V[0], side);
         fdct8<8>(V[0], D[0]);
         return;
     }
@@ -293,7 +313,7 @@ SVS_HD void forward_rows(const uint32_t (&rx)[8], const uint32_t (&ry)[8], float
         vertical_u2_packed(ry, b0, b1);
 #pragma unroll
         for (int x = 0; x < 4; ++x) { V[0][x] = a0[x]; V[1][x] = a1[x]; V[0][4 + x] = b0[x]; V[1][4 + x] = b1[x]; }
-        if (v0) { _Pragma("unroll") for (int x = 0; x < 8; ++x) v0[x] = V[0][x]; }
+        if (side) forward_side(V[0], side);
 #pragma unroll
         for (int u = 0; u < U; ++u) fdct8<8>(V[u], D[u]);
         return;
@@ -311,7 +331,7 @@ SVS_HD void forward_rows(const uint32_t (&rx)[8], const uint32_t (&ry)[8], float
     SVS_COL(0, rx, 0) SVS_COL(1, rx, 1) SVS_COL(2, rx, 2) SVS_COL(3, rx, 3)
     SVS_COL(4, ry, 0) SVS_COL(5, ry, 1) SVS_COL(6, ry, 2) SVS_COL(7, ry, 3)
 #undef SVS_COL
-    if (v0) { _Pragma("unroll") for (int x = 0; x < 8; ++x) v0[x] = V[0][x]; }
+    if (side) forward_side(V[0], side);
 #pragma unroll
     for (int u = 0; u < U; ++u) fdct8<8>(V[u], D[u]);
 }
@@ -406,18 +426,6 @@ SVS_HD uint32_t block_budget(uint64_t first, uint64_t n_bits, uint32_t n) {
     return left < n ? (uint32_t)left : n;
 }
 
-// Flat index 4 (coefficient (0, 4), basis +-1/8) exactly as pocketfft computes it, from row 0 of the vertical pass (which is
-// pocketfft's, see forward_rows): for integer pixels this coefficient is a multiple of 1/8, so c / delta sits EXACTLY on a
-// rounding tie in 1 of 8 delta blocks (SURVEY N6) and only the reference's own float32 sequence says which way it falls.
-// These are the operations of svs::pf::dct2_8 that feed output 4 (radb2 / radb4 sums, one twiddle product), nine in all.
-SVS_HD float pf_row0_coefficient4(const float *v0) {
-    const float c0 = 2.0f * v0[0], c7 = 2.0f * v0[7];
-    const float c1 = v0[1] + v0[2], c3 = v0[3] + v0[4], c5 = v0[5] + v0[6];
-    const float h0 = c0 + c7, h1 = c1 + c5;
-    const float a0 = fmaf(2.0f, c3, h0);
-    return fmaf(-2.0f, h1, a0) * 0x1.6a09e6p-3f;   // r[4] * (float(cos(pi/4)) / 4)
-}
-
 // frac(x) = x - floor(x) in [0, 1) (v_fract_f32) and min(a, |b|, |c|) (one v_min3_f32 with source modifiers)
 SVS_HD float fract_f32(float x) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -460,9 +468,10 @@ SVS_HD bool embed_block(uint32_t (&rx)[8], uint32_t (&ry)[8], uint32_t n_rt, uin
                         const QimParams &qp) {
     static_assert(NFIX == 0 || (U <= 2 && NFIX / 8 + 1 == U), "NFIX must lie in coefficient row U-1, U <= 2");
     const uint32_t n = NFIX ? (uint32_t)NFIX : n_rt;
-    float D[U][8], v0[8];
-    forward_rows<U>(rx, ry, D, v0);
-    if (n >= 4) D[0][4] = pf_row0_coefficient4(v0);   // the reference's own value where exact ties are systematic
+    float D[U][8];
+    ForwardSide side;
+    forward_rows<U>(rx, ry, D, &side);
+    if (n >= 4) D[0][4] = side.c4;   // the reference's own value where exact ties are systematic
     float generic = 0.0f;   // largest min(|c_k|, |change_k|) over the applied coefficients other than 4 / 32 / 36
 
     // QIM on flat coefficients 1..n: force the parity of round(c/delta) to the payload bit by
@@ -593,8 +602,9 @@ template <int U, int QM, int NFIX = 0>
 SVS_HD bool extract_block(const uint32_t (&rx)[8], const uint32_t (&ry)[8], uint32_t n_rt, const QimParams &qp,
                           uint32_t &hi, uint32_t &lo) {
     const uint32_t n = NFIX ? (uint32_t)NFIX : n_rt;
-    float D[U][8], v0[8];
-    forward_rows<U>(rx, ry, D, v0);
+    float D[U][8];
+    ForwardSide side;
+    forward_rows<U>(rx, ry, D, &side);
     hi = 0;
     lo = 0;
     float off = 0.0f;  // largest |t - round(t)| over the used coefficients (0.5 = exactly on a tie)
@@ -603,7 +613,7 @@ SVS_HD bool extract_block(const uint32_t (&rx)[8], const uint32_t (&ry)[8], uint
         if ((uint32_t)k <= n) {  // wave-uniform
             float r;
             if (k == 4) {   // pocketfft's own coefficient: its ties (1 block in 8 delta) are settled here, not redone
-                r = (float)quant_index<QM>(pf_row0_coefficient4(v0), qp);
+                r = (float)quant_index<QM>(side.c4, qp);
             } else {
                 const float t = D[k >> 3][k & 7] * qp.inv_delta_f;
                 r = rintf(t);
@@ -617,8 +627,8 @@ SVS_HD bool extract_block(const uint32_t (&rx)[8], const uint32_t (&ry)[8], uint
     }
     // |t| beyond 2^23 has no fractional part (off == 0) and no tie; NaN cannot occur (finite pixels, delta > 0).
     // The per-block bound wants S = sum of the pixels and their energy Q = sum p^2 through 64 Q - S^2; pixels are at most
-    // 255, so Q <= 255 S and 64 Q - S^2 <= S (16320 - S): no pass over the pixels (S = 8 c00 / a(0)... = v0 summed).
-    const float S = ((v0[0] + v0[1]) + (v0[2] + v0[3]) + (v0[4] + v0[5]) + (v0[6] + v0[7])) * (1.0000005f / SVS_A0);
+    // 255, so Q <= 255 S and 64 Q - S^2 <= S (16320 - S): no pass over the pixels (S = the vertical pass's DC row summed, over a(0)).
+    const float S = side.v0_sum * (1.0000005f / SVS_A0);
     const float spread = guard_sqrt(fmaxf(S * (16320.0f - S), 0.0f)) * 1.000001f;
     const float margin = fmaf(qp.tie2_sum, S, fmaf(qp.tie2_resid, spread, fmaf(D[0][0], qp.tie2_c00, 0x1p-20f)));
     return off >= 0.5f - margin;
