@@ -2,7 +2,7 @@
 """End-to-end example without OpenCV / cryptography: synthetic 1080p clip, a framed payload with the reference's
 wire format (svsdct.framing), embed on the GPU, extract, parse the header, quality metrics on the device.
 
-    python examples/synthetic_roundtrip.py [--mode fast|exact] [--frames 8] [--n-ac 10] [--delta 20]
+    python examples/synthetic_roundtrip.py [--mode guarded|fast|exact] [--frames 8] [--n-ac 10] [--delta 20]
 """
 import argparse
 import ctypes as C
@@ -18,7 +18,7 @@ from svsdct import batch, framing, metrics, native, synth  # noqa: E402
 from svsdct.native import Planes  # noqa: E402
 
 ap = argparse.ArgumentParser()
-ap.add_argument("--mode", default="exact", choices=["fast", "exact"])
+ap.add_argument("--mode", default="guarded", choices=["guarded", "fast", "exact"])
 ap.add_argument("--frames", type=int, default=8)
 ap.add_argument("--n-ac", type=int, default=10)
 ap.add_argument("--delta", type=float, default=20)

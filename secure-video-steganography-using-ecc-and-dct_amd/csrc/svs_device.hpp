@@ -478,7 +478,10 @@ __global__ __launch_bounds__(SVS_WG, SVS_EXACT2_MIN_WAVES) void embed_exact_pair
 // lane loads its own rows before it stores them and touches nobody else's.
 // ---------------------------------------------------------------------------------------
 #ifndef SVS_GUARD_CAP
-#define SVS_GUARD_CAP 32    // worklist entries per wave and round (80 B each)
+#define SVS_GUARD_CAP 32    // worklist entries per wave and round (80 B each) of the one-row (rigorous guard) embed kernel
+#endif
+#ifndef SVS_GUARD_CAP_FAST
+#define SVS_GUARD_CAP_FAST 8   // ... of the kernels with more rows, where undecided blocks are rare outside flat content
 #endif
 
 template <int QM>
@@ -624,7 +627,8 @@ __global__ __launch_bounds__(SVS_WG, (U == 2 ? SVS_U2_MIN_WAVES : (U == 1 && BPL
                                                     const uint32_t *__restrict__ bits, const uint64_t bit_offset,
                                                     const uint64_t n_bits, const uint32_t n_words,
                                                     unsigned long long *__restrict__ replay_counter) {
-    __shared__ GuardEntry entries[SVS_WG / 64][SVS_GUARD_CAP];
+    constexpr int CAP = U == 1 ? SVS_GUARD_CAP : SVS_GUARD_CAP_FAST;
+    __shared__ GuardEntry entries[SVS_WG / 64][CAP];
     __shared__ float tiles[SVS_WG / 64][8 * SVS_GUARD_TILE];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t gblock = (tile_id(g.xcd_chunk) * (uint32_t)SVS_WG + threadIdx.x) * BPL;
@@ -653,8 +657,8 @@ __global__ __launch_bounds__(SVS_WG, (U == 2 ? SVS_U2_MIN_WAVES : (U == 1 && BPL
     }
     const GuardPayload pl{bits, bit_offset, n_bits, n_words};
     const uint64_t first_a = (uint64_t)gblock * n;
-    const uint32_t redone = guard_phase2<QM, BPL == 2>(&entries[wave][0], &tiles[wave][0], lane, n, qp, pl, und_a, first_a, ax, ay,
-                                                       und_b, first_a + n, bx, by);
+    const uint32_t redone = guard_phase2<QM, BPL == 2, CAP>(&entries[wave][0], &tiles[wave][0], lane, n, qp, pl, und_a, first_a, ax, ay,
+                                                            und_b, first_a + n, bx, by);
     if (replay_counter != nullptr && redone != 0 && lane == 0) atomicAdd(replay_counter, (unsigned long long)redone);
     if (write) {
 #pragma unroll

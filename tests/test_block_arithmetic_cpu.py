@@ -174,6 +174,15 @@ def test_forward_transforms_differ_by_less_than_the_tie_bound():
     tb = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(tb)
     assert tb.main() <= float(m.group(1)) * 1.0001                       # the header's constant covers the derived slope
+    # the constants of the per-block margin: at least what tools/guard_bound.py --tie derives for all eight rows
+    kdc = float(re.search(r"#define SVS_TIE2_KDC ([0-9.]+)", text).group(1))
+    ke = float(re.search(r"#define SVS_TIE2_KE ([0-9.]+)", text).group(1))
+    spec = importlib.util.spec_from_file_location("guard_bound", os.path.join(REPO, "tools", "guard_bound.py"))
+    gb = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gb)
+    derived = gb.tie_constants(verbose=False)
+    assert max(v[0] for v in derived.values()) <= kdc and max(v[1] for v in derived.values()) <= ke <= 1.01 * max(v[1] for v in derived.values())
+    ueff = gb.U_EFF
     rng = np.random.default_rng(77)
     blocks = [rng.integers(0, 256, (8, 8)) for _ in range(3000)]
     blocks += [rng.integers(200, 256, (8, 8)) for _ in range(500)] + [rng.integers(0, 8, (8, 8)) for _ in range(200)]
@@ -204,4 +213,8 @@ def test_forward_transforms_differ_by_less_than_the_tie_bound():
         err = np.abs(fast.astype(np.float64) - pf.astype(np.float64)).reshape(-1)[1:].max()
         assert err <= slope * c00, (err, slope * c00)
         worst = max(worst, err / c00)
+        # round 3: the per-block margin the kernels actually test (SVS_TIE2_*), in the form they evaluate it
+        S = float(blk.sum())
+        margin = ueff * (kdc * S / 64.0 + ke * np.sqrt(max(S * (16320.0 - S), 0.0)) / 8.0)
+        assert err <= margin, (err, margin)
     assert worst < slope / 10                                            # the proven bound is >= 10x what occurs
