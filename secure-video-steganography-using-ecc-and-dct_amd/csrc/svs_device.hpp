@@ -615,14 +615,21 @@ __device__ __forceinline__ uint32_t guard_phase2(GuardEntry *entries, float *til
     return total;
 }
 
-#ifndef SVS_U1_MIN_WAVES
-#define SVS_U1_MIN_WAVES 1  // register target of the one-row, two-blocks-per-lane embed kernel (100 VGPRs: 4 waves per SIMD; forcing 5 spills 48 B into the hot path: 2.45 vs 1.65 ms)
+// Register targets (waves per SIMD) of the embed kernels.  With two and more coefficient rows the replay is rare (the two-level
+// guard sends only structured blocks there), so at U = 2 the kernel is allocated for what its HOT path needs - 72 VGPRs (U = 4: 128) - and the inlined
+// replay spills 12 bytes into scratch where it runs: 300 x 1080p n = 10 0.213 vs 0.223 ms,
+// 600 x 4K 1.637 vs 1.689 ms against the natural allocation of 90 VGPRs (profiles/r03_ab_occupancy.txt).  With one row the
+// replay runs in 95 % of the waves and spills there cost far more than the occupancy gains (1.90 vs 1.71 ms): natural allocation.
+#ifndef SVS_U3_MIN_WAVES
+#define SVS_U3_MIN_WAVES 1   // natural allocation (108 VGPRs): 6 waves spill 116 B into the level-2 scan - 1.11 vs 0.79 ms at n = 20
 #endif
 #ifndef SVS_U2_MIN_WAVES
-#define SVS_U2_MIN_WAVES 5  // register target of the two-row embed kernel (92 VGPRs, no scratch; 6 spills 20-52 B)
+#define SVS_U2_MIN_WAVES 7
 #endif
+template <int U>
+constexpr int kEmbedMinWaves = U == 2 ? SVS_U2_MIN_WAVES : U == 3 ? SVS_U3_MIN_WAVES : U == 4 ? 4 : 1;
 template <int U, int QM, int BPL, int NFIX = 0>
-__global__ __launch_bounds__(SVS_WG, (U == 2 ? SVS_U2_MIN_WAVES : (U == 1 && BPL == 2 ? SVS_U1_MIN_WAVES : 1))) void embed_kernel(const uint8_t *gray,
+__global__ __launch_bounds__(SVS_WG, kEmbedMinWaves<U>) void embed_kernel(const uint8_t *gray,
                                                     uint8_t *stego, const Geometry g, const QimParams qp,
                                                     const uint32_t *__restrict__ bits, const uint64_t bit_offset,
                                                     const uint64_t n_bits, const uint32_t n_words,
