@@ -972,11 +972,12 @@ SVS_HD void embed_block_exact(uint32_t (&rx)[8], uint32_t (&ry)[8], uint32_t n, 
 #define SVS_GUARD_DELTA_MIN 0.25
 #define SVS_GUARD_DELTA_MAX 4096.0
 
-// one coefficient row (n <= 7).  On return rx/ry hold the block's stego pixels - or, when the result is true (undecided),
-// its original pixels, untouched.
+// one coefficient row (n <= 7), in two steps.
+// guard_decide: the floor of the change of each of the 8 pixel columns (the same in all 8 rows: only row 0 of the coefficient
+// matrix is touched) and whether the block is undecided; the pixels are not modified.
 template <int QM>
-SVS_HD bool embed_block_guarded(uint32_t (&rx)[8], uint32_t (&ry)[8], uint32_t n, uint32_t nb, uint32_t hi, uint32_t lo,
-                                const QimParams &qp) {
+SVS_HD bool guard_decide(const uint32_t (&rx)[8], const uint32_t (&ry)[8], uint32_t n, uint32_t nb, uint32_t hi, uint32_t lo,
+                         const QimParams &qp, float (&fl)[8]) {
     // vertical pass, row 0 only: pocketfft's X[0] of a column of integers is fl(colsum * sqrt(2)/4) - its sums are exact
     // integers and the one product rounds once - which is what the packed 16-bit column sums give (SVS_A0 is that float)
     float V[8];
@@ -1022,21 +1023,33 @@ SVS_HD bool embed_block_guarded(uint32_t (&rx)[8], uint32_t (&ry)[8], uint32_t n
     // BETA for this block: 64 Q - S^2 = 64 * (sum of squared deviations from the mean), an exact integer < 2^32
     const float spread = guard_sqrt((float)(64u * Q - S * S));
     const float beta = fmaf(qp.g_sum, (float)S, fmaf(qp.g_resid, spread, qp.g_delta));
-    float fl[8], worst = 0.0f;   // floor of the 8 column changes; largest |frac(change) - 1/2| among them
+    float worst = 0.0f;   // largest |frac(change) - 1/2| among the 8 columns
 #pragma unroll
     for (int x = 0; x < 8; ++x) {
         const float ch = P[x] * SVS_A0;
         fl[x] = floorf(ch);
         worst = fmaxf(worst, fabsf((ch - fl[x]) - 0.5f));
     }
-    const bool undecided = nb > 0 && !(worst < 0.5f - beta);   // nb == 0: the reference never enters the block (:130,:132)
-    if (!undecided) {   // an undecided block keeps its original pixels: the caller hands them to the exact arithmetic
+    return nb > 0 && !(worst < 0.5f - beta);   // nb == 0: the reference never enters the block (:130,:132)
+}
+
+// the cheap result: pixel + floor(change of its column), saturated (trunc(clip(x + c)) == clip(x + floor(c)) for integer x, :171)
+SVS_HD void guard_apply(uint32_t (&rx)[8], uint32_t (&ry)[8], const float (&fl)[8]) {
 #define SVS_OUTCOL(X, W, B)                                                           \
     _Pragma("unroll") for (int y = 0; y < 8; ++y) W[y] = put_pixel<B>(ubyte_to_float<B>(W[y]) + fl[X], W[y]);
-        SVS_OUTCOL(0, rx, 0) SVS_OUTCOL(1, rx, 1) SVS_OUTCOL(2, rx, 2) SVS_OUTCOL(3, rx, 3)
-        SVS_OUTCOL(4, ry, 0) SVS_OUTCOL(5, ry, 1) SVS_OUTCOL(6, ry, 2) SVS_OUTCOL(7, ry, 3)
+    SVS_OUTCOL(0, rx, 0) SVS_OUTCOL(1, rx, 1) SVS_OUTCOL(2, rx, 2) SVS_OUTCOL(3, rx, 3)
+    SVS_OUTCOL(4, ry, 0) SVS_OUTCOL(5, ry, 1) SVS_OUTCOL(6, ry, 2) SVS_OUTCOL(7, ry, 3)
 #undef SVS_OUTCOL
-    }
+}
+
+// decide, then apply: on return rx/ry hold the block's stego pixels - or, when the result is true (undecided), its original
+// pixels, untouched (the host emulation and the in-place / fused-colour kernels)
+template <int QM>
+SVS_HD bool embed_block_guarded(uint32_t (&rx)[8], uint32_t (&ry)[8], uint32_t n, uint32_t nb, uint32_t hi, uint32_t lo,
+                                const QimParams &qp) {
+    float fl[8];
+    const bool undecided = guard_decide<QM>(rx, ry, n, nb, hi, lo, qp, fl);
+    if (!undecided) guard_apply(rx, ry, fl);
     return undecided;
 }
 
