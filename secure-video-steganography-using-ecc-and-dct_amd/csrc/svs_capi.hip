@@ -180,6 +180,18 @@ int launch_embed(int rows, uint64_t total, hipStream_t st, const uint8_t *gray, 
     return SVS_OK;
 }
 
+// GUARDED with two coefficient rows (n = 8..15): the streaming kernel with the per-pixel rigorous guard
+template <int QM>
+int launch_embed_guarded2(uint64_t total, hipStream_t st, const uint8_t *gray, uint8_t *stego, const svs::Geometry &g,
+                          const svs::QimParams &qp, const uint32_t *bits, uint64_t bit_offset, uint64_t n_bits, uint32_t n_words) {
+    const dim3 grid((uint32_t)((total + SVS_WG - 1) / SVS_WG));
+    const uint32_t lds_pad = lds_pad_for(env_chunk("SVS_EMBED_WG_PER_CU", 0), kEmbedLds);
+    hipLaunchKernelGGL((svs::embed_kernel<2, QM, 1, 0, true>), grid, dim3(SVS_WG), lds_pad, st, gray, stego, g, qp, bits, bit_offset,
+                       n_bits, n_words, g_guard_counter);
+    SVS_HIP(hipGetLastError());
+    return SVS_OK;
+}
+
 template <int QM, int BPL>
 int launch_extract(int rows, uint64_t total, hipStream_t st, const uint8_t *gray, const svs::Geometry &g,
                    const svs::QimParams &qp, uint8_t *out, uint64_t out_bytes) {
@@ -451,6 +463,22 @@ int svs_embed_dev(const uint8_t *d_gray, uint8_t *d_stego, const svs_planes *pla
     // Outside the delta range the guard is useless (every block undecided below, BETA > 1/8 above): exact kernels.
     const bool in_range = delta >= SVS_GUARD_DELTA_MIN && delta <= SVS_GUARD_DELTA_MAX;
     bool streaming = use > 0 && in_range && !(flags & SVS_EXACT_POCKETFFT) && (rows == 1 || !(flags & SVS_EXACT_GUARDED));
+    const bool guarded2 = use > 0 && in_range && (flags & SVS_EXACT_GUARDED) && !(flags & SVS_EXACT_POCKETFFT) && rows == 2 &&
+                          env_chunk("SVS_GUARDED2_OFF", 0) == 0;
+    if (guarded2) {   // bit-identical at n = 8..15 through the streaming kernel with the per-pixel rigorous guard
+        const uint64_t words_g = ((bit_offset + use + 7) / 8 + 3) / 4;
+        if (words_g >= (1ull << 32)) return fail(SVS_ERR_INVALID_ARG, "payload too large for one call");
+        svs::make_guard(delta, 2, &qp);
+        g.xcd_chunk = env_chunk("SVS_EMBED_XCD_CHUNK", kEighth);
+        const uint32_t *bwg = reinterpret_cast<const uint32_t *>(d_bits_packed);
+        int rcg;
+        if (qm == svs::QM_DOUBLE) rcg = launch_embed_guarded2<svs::QM_DOUBLE>(total, st, d_gray, d_stego, g, qp, bwg, bit_offset, use, (uint32_t)words_g);
+        else if (qm == svs::QM_POW2) rcg = launch_embed_guarded2<svs::QM_POW2>(total, st, d_gray, d_stego, g, qp, bwg, bit_offset, use, (uint32_t)words_g);
+        else rcg = launch_embed_guarded2<svs::QM_F32>(total, st, d_gray, d_stego, g, qp, bwg, bit_offset, use, (uint32_t)words_g);
+        if (rcg) return rcg;
+        if (n_embedded) *n_embedded = use;
+        return SVS_OK;
+    }
     // (the streaming kernel stays ahead of the lane-per-block pocketfft kernel up to all eight coefficient rows: 1.20 vs
     // 1.33 ms per 200 x 4K frames at n = 63, profiles/r03_many_coefficients.txt; SVS_FAST_MAX_ROWS is the A/B knob)
     if (rows > (int)env_chunk("SVS_FAST_MAX_ROWS", 8)) streaming = false;

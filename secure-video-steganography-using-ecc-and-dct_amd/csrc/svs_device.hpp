@@ -541,7 +541,7 @@ __device__ __forceinline__ void guard_replay8(GuardEntry *e, float *t, uint32_t 
 
 // phase 1 for one block whose rows are ax/ay, in place: stego pixels out - unless the block is undecided, then its original
 // pixels are left untouched (svs_block.hpp decides before it writes).  -> undecided
-template <int U, int QM, int NFIX>
+template <int U, int QM, int NFIX, bool RIG = false>
 __device__ __forceinline__ bool guard_phase1(uint32_t (&ax)[8], uint32_t (&ay)[8], uint32_t n, uint64_t first,
                                              const QimParams &qp, const uint32_t *__restrict__ bits,
                                              uint64_t bit_offset, uint64_t n_bits, uint32_t n_words) {
@@ -549,6 +549,7 @@ __device__ __forceinline__ bool guard_phase1(uint32_t (&ax)[8], uint32_t (&ay)[8
     payload_window(bits, n_words, bit_offset + first, hi, lo);
     const uint32_t nb = block_budget(first, n_bits, n);
     if constexpr (U == 1) return embed_block_guarded<QM>(ax, ay, n, nb, hi, lo, qp);
+    else if constexpr (U == 2 && RIG) return embed_block_guarded2<QM>(ax, ay, n, nb, hi, lo, qp);   // GUARDED, n = 8..15
     else return embed_block<U, QM, NFIX>(ax, ay, n, nb, hi, lo, qp);
 }
 
@@ -628,13 +629,17 @@ __device__ __forceinline__ uint32_t guard_phase2(GuardEntry *entries, float *til
 #endif
 template <int U>
 constexpr int kEmbedMinWaves = U == 2 ? SVS_U2_MIN_WAVES : U == 3 ? SVS_U3_MIN_WAVES : U == 4 ? 4 : 1;
-template <int U, int QM, int BPL, int NFIX = 0>
-__global__ __launch_bounds__(SVS_WG, kEmbedMinWaves<U>) void embed_kernel(const uint8_t *gray,
+// index for __launch_bounds__ below (a macro argument cannot hold the comma of a second template argument): the rigorous
+// two-row kernel replays in every wave (about 15 % of noise blocks are undecided), so it keeps its natural allocation
+template <int UR>
+constexpr int kEmbedMinWavesRig = UR >= 100 ? 1 : kEmbedMinWaves<UR>;
+template <int U, int QM, int BPL, int NFIX = 0, bool RIG = false>
+__global__ __launch_bounds__(SVS_WG, kEmbedMinWavesRig<U + (RIG ? 100 : 0)>) void embed_kernel(const uint8_t *gray,
                                                     uint8_t *stego, const Geometry g, const QimParams qp,
                                                     const uint32_t *__restrict__ bits, const uint64_t bit_offset,
                                                     const uint64_t n_bits, const uint32_t n_words,
                                                     unsigned long long *__restrict__ replay_counter) {
-    constexpr int CAP = U == 1 ? SVS_GUARD_CAP : SVS_GUARD_CAP_FAST;
+    constexpr int CAP = (U == 1 || RIG) ? SVS_GUARD_CAP : SVS_GUARD_CAP_FAST;
     __shared__ GuardEntry entries[SVS_WG / 64][CAP];
     __shared__ float tiles[SVS_WG / 64][8 * SVS_GUARD_TILE];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -656,9 +661,9 @@ __global__ __launch_bounds__(SVS_WG, kEmbedMinWaves<U>) void embed_kernel(const 
         write = stego != gray;                         // past the budget: byte-identical copy (the reference's loops `break`, :130,:132)
         if (first < n_bits) {
             write = true;
-            und_a = guard_phase1<U, QM, NFIX>(ax, ay, n, first, qp, bits, bit_offset, n_bits, n_words);
+            und_a = guard_phase1<U, QM, NFIX, RIG>(ax, ay, n, first, qp, bits, bit_offset, n_bits, n_words);
             if constexpr (BPL == 2) {   // a budget of 0 (only the lane the payload ends in can see it) leaves block B as it is
-                if (first + n < n_bits) und_b = guard_phase1<U, QM, NFIX>(bx, by, n, first + n, qp, bits, bit_offset, n_bits, n_words);
+                if (first + n < n_bits) und_b = guard_phase1<U, QM, NFIX, RIG>(bx, by, n, first + n, qp, bits, bit_offset, n_bits, n_words);
             }
         }
     }

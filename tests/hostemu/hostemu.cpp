@@ -65,6 +65,11 @@ bool g_constant_shortcut = false;   // exact == 3: constant blocks take forward_
 
 // GUARDED (exact == 4, one coefficient row): -> true when the block has to be redone with the exact arithmetic
 bool embed_guarded_dispatch(Blk &raw, uint32_t n, uint32_t nb, uint32_t hi, uint32_t lo, const svs::QimParams &qp, int qm) {
+    if (svs::rows_for((int)n) == 2) {   // two coefficient rows: the per-pixel rigorous guard
+        if (qm == svs::QM_DOUBLE) return svs::embed_block_guarded2<svs::QM_DOUBLE>(raw.x, raw.y, n, nb, hi, lo, qp);
+        if (qm == svs::QM_POW2) return svs::embed_block_guarded2<svs::QM_POW2>(raw.x, raw.y, n, nb, hi, lo, qp);
+        return svs::embed_block_guarded2<svs::QM_F32>(raw.x, raw.y, n, nb, hi, lo, qp);
+    }
     if (qm == svs::QM_DOUBLE) return svs::embed_block_guarded<svs::QM_DOUBLE>(raw.x, raw.y, n, nb, hi, lo, qp);
     if (qm == svs::QM_POW2) return svs::embed_block_guarded<svs::QM_POW2>(raw.x, raw.y, n, nb, hi, lo, qp);
     return svs::embed_block_guarded<svs::QM_F32>(raw.x, raw.y, n, nb, hi, lo, qp);
@@ -125,8 +130,9 @@ uint64_t emu_embed(const uint8_t *gray, uint8_t *stego, int F, int H, int W, dou
     // FAST (exact == 0) takes the same kernel for one coefficient row; with more rows it runs the FMA-factored kernels with
     // their per-pixel guard.  Outside the delta range both modes run the exact kernels.
     const bool in_range = delta >= SVS_GUARD_DELTA_MIN && delta <= SVS_GUARD_DELTA_MAX;
-    const bool guarded = (exact == 4 || exact == 0) && use > 0 && svs::rows_for(n) == 1 && in_range;
-    if (guarded) svs::make_guard(delta, 1, &qp);
+    const bool guarded = use > 0 && in_range &&
+                         (((exact == 4 || exact == 0) && svs::rows_for(n) == 1) || (exact == 4 && svs::rows_for(n) == 2));
+    if (guarded) svs::make_guard(delta, svs::rows_for(n), &qp);
     if (exact == 4 && !guarded) exact = 1;
     if (exact == 0 && !in_range) exact = 1;   // svs_embed_dev: out-of-range delta
     if (use == 0) {

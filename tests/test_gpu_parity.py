@@ -160,7 +160,8 @@ def test_fast_mode_contract_on_structured_content(n_ac, delta):
 
 @pytest.mark.parametrize("n_ac,delta", GUARDED_POINTS)
 def test_guarded_mode_equals_reference_on_structured_content(n_ac, delta):
-    """the streaming kernel with its rigorous guard is the reference, pixel for pixel, on 14 content
+    """the streaming kernel with its rigorous guard (8 tests per block at n <= 7, 64 at n = 8..15) is the
+    reference, pixel for pixel, on 14 content
     classes (flat, letterboxed, one-dimensional, posterised, text-like, dark / bright noise, exact cancellations ...) at
     every setting incl. the ends of its delta range; the share of blocks it redid exactly is recorded per class."""
     lib = native.load()
@@ -180,14 +181,16 @@ def test_guarded_mode_equals_reference_on_structured_content(n_ac, delta):
             lib.svs_guard_counter_set(None)
         _, ref, ref_used = orc.frame_embed(cover, delta, payload, n_ac)
         assert used == ref_used and np.array_equal(stego[0], ref), name
-        fast, used_f = batch.embed_frames(cover, delta, n_ac, payload, mode="fast")      # n <= 7: the same launch
-        assert used_f == ref_used and np.array_equal(fast[0], ref), name
+        if n_ac <= 7:
+            fast, used_f = batch.embed_frames(cover, delta, n_ac, payload, mode="fast")  # n <= 7: the same launch
+            assert used_f == ref_used and np.array_equal(fast[0], ref), name
         _REPORT[f"guarded/{name}_n{n_ac}_d{delta:g}"] = {
             "pixels": h * w, "pixels_differing_from_reference": 0,
             "blocks_redone_exactly_share": int(d_cnt.get(8, np.uint64)[0]) / (cap // n_ac)}
 
 
-@pytest.mark.parametrize("f,h,w,n_ac,delta", [(600, 2160, 3840, 3, 8.0), (300, 1080, 1920, 7, 4.0), (150, 4320, 7680, 1, 16.0)])
+@pytest.mark.parametrize("f,h,w,n_ac,delta", [(600, 2160, 3840, 3, 8.0), (300, 1080, 1920, 7, 4.0), (150, 4320, 7680, 1, 16.0),
+                                              (300, 1080, 1920, 10, 8.0), (150, 2160, 3840, 15, 20.0)])
 def test_guarded_mode_full_batch_equals_exact_kernel_on_device(f, h, w, n_ac, delta):
     """BASELINE batch sizes, device-resident: the streaming kernel's output has zero squared difference to the
     lane-per-block pocketfft kernel's on every frame (5 Gpixel per case), in place as well."""

@@ -39,6 +39,13 @@ def test_header_constants_cover_the_derived_bound():
     k7 = gb.analyse(7, verbose=False)
     for name, val in (("SVS_GUARD_KDC", k7["kdc"]), ("SVS_GUARD_KE", k7["ke"]), ("SVS_GUARD_KD_U1", k7["kd"])):
         assert val <= have[name] <= val * 1.01 + 1e-3, (name, have[name], val)
+    k15 = gb.analyse(15, verbose=False)
+    assert k15["kd"] <= have["SVS_GUARD_KD_U2"] <= k15["kd"] * 1.01 + 1e-3 and k15["ke"] <= have["SVS_GUARD_KE"]
+    text = open(os.path.join(CSRC, "svs_block.hpp")).read()
+    cc = float(re.search(r"#define SVS_GUARD_KE_CC ([0-9.]+)", text).group(1))
+    ce = float(re.search(r"#define SVS_GUARD_KE_CE ([0-9.]+)", text).group(1))
+    assert k15["ke_classes"]["cc"] <= cc <= 1.01 * k15["ke_classes"]["cc"] and k15["ke_classes"]["ce"] <= ce <= 1.01 * k15["ke_classes"]["ce"]
+    assert k15["ke_classes"]["ee"] <= have["SVS_GUARD_KE"]
     assert k7["ke_lo"] > 0.5 * k7["ke"]      # the Cauchy-Schwarz bound on the (2 -> 1) norm is within 2x of a lower bound
 
 
@@ -88,7 +95,7 @@ def test_guarded_equals_exact_on_structured_content(n_ac, delta):
             assert used == ref_used and np.array_equal(got[0], ref), (name, fill)
             if fill is None:
                 shares[name] = redone[0] / (cap // n_ac)
-    if 1 <= delta <= 100:                                                # the GUI's range (app.py:232)
+    if 1 <= delta <= 100 and n_ac <= 7:                                  # the GUI's range (app.py:232); one row: 8 tests per block
         assert shares["ramp"] < 0.2 and shares["dark_noise_0_3"] < 0.2  # the guard decides most blocks of ordinary content
 
 
@@ -113,10 +120,10 @@ def test_noise_content_share_and_partial_budgets():
 
 
 def test_outside_the_guarded_domain_the_exact_arithmetic_runs():
-    """n_ac >= 8, delta outside [0.25, 4096], delta <= 0: the flag is still valid and the result is the reference's"""
+    """n_ac >= 16, delta outside [0.25, 4096], delta <= 0: the flag is still valid and the result is the reference's"""
     rng = np.random.default_rng(6)
     frames = rng.integers(0, 256, (1, 48, 64), dtype=np.uint8)
-    for n_ac, delta in ((10, 8), (63, 4), (3, 0.01), (3, 1e5), (3, 0), (0, 8), (8, 8)):
+    for n_ac, delta in ((16, 8), (63, 4), (3, 0.01), (3, 1e5), (10, 0.01), (3, 0), (0, 8), (24, 8)):
         cap = 6 * 8 * max(0, min(n_ac, 63))
         bits = rng.integers(0, 2, max(cap, 1)).astype(np.uint8)
         redone = []
@@ -126,7 +133,7 @@ def test_outside_the_guarded_domain_the_exact_arithmetic_runs():
 
 
 @settings(max_examples=60, deadline=None)
-@given(st.integers(0, 2 ** 32 - 1), st.integers(1, 7), st.sampled_from([0.25, 0.5, 1, 2, 3, 4, 7.5, 8, 16, 20, 100, 1000]),
+@given(st.integers(0, 2 ** 32 - 1), st.integers(1, 15), st.sampled_from([0.25, 0.5, 1, 2, 3, 4, 7.5, 8, 16, 20, 100, 1000]),
        st.sampled_from(["full", "narrow", "flat", "columns", "rows", "binary"]))
 def test_guarded_equals_oracle_hypothesis(seed, n_ac, delta, kind):
     rng = np.random.default_rng(seed)

@@ -64,8 +64,9 @@ ORIGINAL_COVERS = ("natural_like", "flat_128", "constant_rows", "constant_column
 # (n_ac, delta) points of the FAST-mode contract checks on structured content plus the settings at
 # which the index-4 / two-row coincidences are largest; (1, 8), (16, 8), (36, 8), (63, 4) added after VERDICT r02 next #3
 CONTRACT_POINTS = [(3, 8), (3, 16), (7, 4), (10, 20), (4, 8), (8, 4), (8, 2), (1, 8), (16, 8), (36, 8), (63, 4), (9, 8)]
-# (n_ac, delta) points of the GUARDED-mode identity checks (one coefficient row; the ends of the delta range included)
-GUARDED_POINTS = [(3, 8), (1, 8), (7, 4), (4, 8), (3, 16), (5, 0.5), (2, 0.25), (3, 100), (7, 4096), (6, 7.3)]
+# (n_ac, delta) points of the GUARDED-mode identity checks (one and two coefficient rows; the ends of the delta range included)
+GUARDED_POINTS = [(3, 8), (1, 8), (7, 4), (4, 8), (3, 16), (5, 0.5), (2, 0.25), (3, 100), (7, 4096), (6, 7.3),
+                  (10, 8), (8, 4), (15, 20), (12, 0.5), (9, 100), (10, 4096)]
 
 
 def sha(a):

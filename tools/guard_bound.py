@@ -386,13 +386,73 @@ def op_norm_2_to_1(M, iters=12):
     return best * (1 + 1e-9), lo
 
 
+def idct8_tape(t, X, skip0):
+    """svs::idct8<8, SKIP0> (csrc/svs_block.hpp), FMA form; X[k] may be None (known zero)"""
+    def m(a, c):
+        return None if a is None else t.mulc(a, c)
+
+    def f(a, c, b):           # fma(a, c, b) with possibly-zero operands
+        if a is None:
+            return b
+        return t.mulc(a, c) if b is None else t.fmac(a, c, b)
+
+    def plus(a, b, sign=1.0):
+        if a is None and b is None:
+            return None
+        if b is None:
+            return a
+        if a is None:
+            return b if sign > 0 else t.mul_pow2(b, -1.0)
+        return t.add(a, b, sign)
+    p = None if skip0 else m(X[0], A0)
+    r = m(X[4], CK[4])
+    a, b = plus(p, r), plus(p, r, -1.0)
+    g0, g1 = m(X[2], CK[2]), m(X[2], CK[6])
+    g0, g1 = f(X[6], CK[6], g0), f(X[6], -CK[2], g1)
+    e0, e3, e1, e2 = plus(a, g0), plus(a, g0, -1.0), plus(b, g1), plus(b, g1, -1.0)
+    o = [m(X[1], CK[1]), m(X[1], CK[3]), m(X[1], CK[5]), m(X[1], CK[7])]
+    for (k, cs) in ((3, (CK[3], -CK[7], -CK[1], -CK[5])), (5, (CK[5], -CK[1], CK[7], CK[3])), (7, (CK[7], -CK[5], CK[3], -CK[1]))):
+        o = [f(X[k], cs[i], o[i]) for i in range(4)]
+    e = [e0, e1, e2, e3]
+    x = [None] * 8
+    for i in range(4):
+        x[i], x[7 - i] = plus(e[i], o[i]), plus(e[i], o[i], -1.0)
+    return x
+
+
 def sparse_inverse_terms(nb, rows):
     """The kernel's own side of the comparison, per unit of dmax (everything here is proportional to the coefficient
-    changes): change_k = fl(cn_k - D_k) carries one rounding; the sparse inverse (svs::idct8 FMA forms, then the vertical
-    products) performs at most `ops` roundings on the way to a pixel, each of a partial sum that is bounded by the sum of
-    the absolute terms, i.e. by nb * dmax * max|basis product| * 4 (the factor covers unnormalised intermediates)."""
-    ops = 2 * (8 + 2 * rows) + 6
-    return nb * 0.25 + ops * nb * 0.5 * 2.0
+    changes): change_k = fl(cn_k - D_k) carries one rounding (kappa 1 on the input), the sparse inverse (svs::idct8 FMA forms
+    on the rows, then the vertical products) is recorded on a tape like the reference's transforms.  Rows 1 and 2 are
+    modelled exactly; more rows fall back to a crude count (at most `ops` roundings of partial sums bounded by the sum of
+    the absolute terms)."""
+    if rows > 2:
+        ops = 2 * (8 + 2 * rows) + 6
+        return nb * 0.25 + ops * nb * 0.5 * 2.0
+    t = Tape()
+    ch = {}
+    for k in range(1, nb + 1):
+        w = np.zeros(NSYM)
+        w[64 + k - 1] = 1.0
+        ch[k] = t.node(w, [], 1)          # the rounding of cn_k - D_k
+    P0 = idct8_tape(t, [None] + [ch.get(k) for k in range(1, 8)], True)
+    P1 = idct8_tape(t, [ch.get(8 + v) for v in range(8)], False) if rows == 2 else [None] * 8
+    worst = 0.0
+    cv = [CK[1], CK[3], CK[5], CK[7], -CK[7], -CK[5], -CK[3], -CK[1]]
+    for x in range(8):
+        base = None if P0[x] is None else t.mulc(P0[x], A0)
+        for y in range(8 if rows == 2 else 1):
+            node = base
+            if rows == 2 and P1[x] is not None:
+                node = t.mulc(P1[x], cv[y]) if base is None else t.fmac(P1[x], cv[y], base)
+            if node is None:
+                continue
+            seed = np.zeros(64)
+            seed[0] = 1.0
+            G = gains(t, {node: seed})[:, 0]
+            W = np.array(t.w)[:, 64:]
+            worst = max(worst, float((np.array(t.kappa, float) * np.abs(G) * np.abs(W).sum(axis=1)).sum()))
+    return worst
 
 
 def analyse(nb, verbose=True):
@@ -406,7 +466,7 @@ def analyse(nb, verbose=True):
     Rf = Wf[:, :64] - sf[:, None] / 64.0           # mean-free part (R is orthogonal to the constant)
     Ri = Wi[:, :64] - si[:, None] / 64.0
     Di = np.abs(Wi[:, 64:]).sum(axis=1)
-    worst = dict(kdc=0.0, ke=0.0, kd=0.0, ke_lo=0.0)
+    worst = dict(kdc=0.0, ke=0.0, kd=0.0, ke_lo=0.0, ke_by_output=[0.0] * 64)
     rows = (nb >> 3) + 1
     for o in range(64):
         gf = kf * np.abs(Gf[:, o])
@@ -415,14 +475,22 @@ def analyse(nb, verbose=True):
         kd = (gi * Di).sum() + sparse_inverse_terms(nb, rows)
         M = np.vstack([Rf * gf[:, None], Ri * gi[:, None]])
         ke, ke_lo = op_norm_2_to_1(M)
+        worst["ke_by_output"][o] = ke
         worst["kdc"] = max(worst["kdc"], kdc)
         worst["kd"] = max(worst["kd"], kd)
         if ke > worst["ke"]:
             worst["ke"], worst["ke_lo"] = ke, ke_lo
+    # position classes (embed_block_guarded2): rows / columns {0, 3, 4, 7} = "c", {1, 2, 5, 6} = "e"
+    cls = lambda i: "c" if i in (0, 3, 4, 7) else "e"
+    by = {"cc": 0.0, "ce": 0.0, "ee": 0.0}
+    for o in range(64):
+        key = "".join(sorted(cls(o // 8) + cls(o % 8)))
+        by[key] = max(by[key], worst["ke_by_output"][o])
+    worst["ke_classes"] = by
     if verbose:
         n_round = int((kf > 0).sum() + (ki > 0).sum())
-        print("nb = %2d: %d rounding operations on the tapes;  KDC = %.3f   KE = %.3f (lower bound %.3f)   KD = %.3f" %
-              (nb, n_round, worst["kdc"], worst["ke"], worst["ke_lo"], worst["kd"]))
+        print("nb = %2d: %d rounding operations on the tapes;  KDC = %.3f   KE = %.3f (lower bound %.3f; by position class cc %.2f ce %.2f ee %.2f)   KD = %.3f" %
+              (nb, n_round, worst["kdc"], worst["ke"], worst["ke_lo"], by["cc"], by["ce"], by["ee"], worst["kd"]))
     return worst
 
 
