@@ -364,9 +364,9 @@ struct QimParams {
 // with ||X - mean||_2^2 = Q - S^2/64 <= S (16320 - S) / 64 (pixels <= 255), so that the block's pixel sum S is all it takes:
 // 4x tighter than the global slope at mean 128 (3.5e-3 -> never-embedded noise: 0.7 % of the blocks at n = 10, delta = 8
 // instead of 4 %).  Flat index 4 does not enter: its value is pocketfft's own (pf_row0_coefficient4).
-// Constants of the largest row count (U = 8; U = 2: KE 28.6):
+// Constants of the largest row count (U = 8; U = 2: KE 24.3):
 #define SVS_TIE2_KDC 64.0001
-#define SVS_TIE2_KE 30.14
+#define SVS_TIE2_KE 25.92
 
 // How the quantiser is evaluated (all three give the reference's result, they differ in cost):
 //   QM_F32    general delta: IEEE float32 division (about 10 instructions), float32 requantisation
@@ -963,7 +963,7 @@ SVS_HD void embed_block_exact(uint32_t (&rx)[8], uint32_t (&ry)[8], uint32_t n, 
 // noise block (mean 128, sigma 65, delta 8) is flagged with probability 16 * BETA = 2.4 %; smooth content 0.6 %.
 // Constants printed by tools/guard_bound.py (tests/test_guard_bound_cpu.py re-derives them):
 #define SVS_GUARD_KDC 17.0001      // per unit of the mean pixel value
-#define SVS_GUARD_KE 39.40         // per unit of ||X - mean||_2
+#define SVS_GUARD_KE 31.05         // per unit of ||X - mean||_2 (the (2 -> 1) norm is at least 30.66: the bound is tight)
 #define SVS_GUARD_KD_U1 19.61      // per unit of 1.5 delta + 0.01, at most 7 modified coefficients (incl. the kernel's own sparse inverse)
 #define SVS_GUARD_KD_U2 54.78      // at most 15 modified coefficients
 #define SVS_GUARD_UEFF (5.9604644775390625e-8 * (1.0 + 0.0009765625))
@@ -1056,13 +1056,13 @@ SVS_HD bool embed_block_guarded(uint32_t (&rx)[8], uint32_t (&ry)[8], uint32_t n
 // Two coefficient rows (n = 8..15), rigorous: the same construction with 64 predictions instead of 8 (the change now varies
 // down a column) - pocketfft-identical rows 0 and 1 (the vertical pass is pocketfft's dct2_8 per column, of which the compiler
 // keeps the operations behind outputs 0 and 1), QIM with the reference's decisions, sparse inverse, and every pixel's
-// prediction tested against the grid with the bound of ITS position: the (2 -> 1) norms behind KE differ by pixel (25.3 in
-// rows / columns 0, 3, 4, 7 crossed with each other, 39.4 in rows / columns 1, 2, 5, 6 crossed, 35.2 mixed), which takes the
-// share of undecided noise blocks from 18 % to 16 %.  The prediction is read from the value the store path feeds to
+// prediction tested against the grid with the bound of ITS position: the (2 -> 1) norms behind KE differ by pixel (24.7 in
+// rows / columns 0, 3, 4, 7 crossed with each other, 31.0 in rows / columns 1, 2, 5, 6 crossed, 27.9 mixed), which takes the
+// share of undecided noise blocks from 13 % to 12 %.  The prediction is read from the value the store path feeds to
 // v_cvt_pk_u8_f32 (pixel + change - (1/2 - 2^-16), see embed_block): two float32 roundings at magnitude < 512, for which
 // make_guard adds 2^-14 to BETA.
-#define SVS_GUARD_KE_CC 25.27
-#define SVS_GUARD_KE_CE 35.16
+#define SVS_GUARD_KE_CC 24.68
+#define SVS_GUARD_KE_CE 27.93
 template <int QM>
 SVS_HD bool embed_block_guarded2(uint32_t (&rx)[8], uint32_t (&ry)[8], uint32_t n, uint32_t nb, uint32_t hi, uint32_t lo,
                                  const QimParams &qp) {

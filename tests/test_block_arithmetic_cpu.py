@@ -180,7 +180,7 @@ def test_forward_transforms_differ_by_less_than_the_tie_bound():
     spec = importlib.util.spec_from_file_location("guard_bound", os.path.join(REPO, "tools", "guard_bound.py"))
     gb = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(gb)
-    derived = gb.tie_constants(verbose=False)
+    derived = gb.tie_constants(verbose=False, rows_list=(2, 8))      # monotone in the row count (tools/guard_bound.py --tie)
     assert max(v[0] for v in derived.values()) <= kdc and max(v[1] for v in derived.values()) <= ke <= 1.01 * max(v[1] for v in derived.values())
     ueff = gb.U_EFF
     rng = np.random.default_rng(77)
