@@ -16,12 +16,14 @@ TAG=r3n3 BENCH_ARGS="--frames 600" bash tools/gpu_pmc_sq.sh > $E/sq_run.log 2>&1
 TAG=r3n10 BENCH_ARGS="--frames 600 --n-ac 10" bash tools/gpu_pmc_sq.sh >> $E/sq_run.log 2>&1; python tools/sq_summary.py r3n10 > $E/sq_counters_n10.txt 2>&1
 TAG=r3n63 BENCH_ARGS="--frames 200 --n-ac 63" bash tools/gpu_pmc_sq.sh >> $E/sq_run.log 2>&1; python tools/sq_summary.py r3n63 > $E/sq_counters_n63.txt 2>&1
 : > $E/other_configs_bench.jsonl
-for cfg in "--frames 300 --height 1080 --width 1920 --n-ac 10 --delta 8" "--frames 600 --n-ac 10" "--frames 150 --height 4320 --width 7680 --delta 4" "--frames 150 --height 4320 --width 7680 --delta 8" "--frames 150 --height 4320 --width 7680 --delta 16" "--frames 120 --height 480 --width 640 --n-ac 10 --delta 20" "--frames 200 --n-ac 63" "--frames 600 --mode exact"; do
+for cfg in "--frames 300 --height 1080 --width 1920 --n-ac 10 --delta 8" "--frames 600 --n-ac 10" "--frames 150 --height 4320 --width 7680 --delta 4" "--frames 150 --height 4320 --width 7680 --delta 8" "--frames 150 --height 4320 --width 7680 --delta 16" "--frames 120 --height 480 --width 640 --n-ac 10 --delta 20" "--frames 200 --n-ac 63" "--frames 600 --mode exact" "--frames 600 --n-ac 10 --mode guarded" "--frames 300 --height 1080 --width 1920 --n-ac 10 --delta 8 --mode guarded"; do
   timeout -k 10 300 python bench.py $cfg --cpu-frames 0 --steps 20 2>/dev/null | grep '^{' >> $E/other_configs_bench.jsonl
 done
 step 600 guarded_probe_n3.txt python tools/guarded_probe.py --frames 200 --json $E/guarded_probe_n3.json
 step 300 guarded_probe_n1.txt python tools/guarded_probe.py --frames 200 --n-ac 1 --classes noise,natural,flat128,letterbox25
 step 300 guarded_probe_n7.txt python tools/guarded_probe.py --frames 200 --n-ac 7 --classes noise,natural,flat128,letterbox25
+step 400 guarded_probe_n10.txt python tools/guarded_probe.py --frames 200 --n-ac 10 --classes noise,natural,flat128,letterbox25,rows,checker8,dark,bright
+step 300 guarded_probe_n15.txt python tools/guarded_probe.py --frames 200 --n-ac 15 --delta 20 --classes noise,natural
 step 300 tie_fallback_new.txt python tools/tie_fallback_rate.py
 SVSDCT_LIB=$V/variants/libsvsdct_r02.so SVS_SKIP_ABI_CHECK=1 timeout -k 10 300 python tools/tie_fallback_rate.py > $E/tie_fallback_r02.txt 2>&1
 : > $E/ab_vs_r02.txt
