@@ -93,15 +93,29 @@ def _cpu_worker(task):
     return time.perf_counter() - t0, int((got != bits).sum())
 
 
+_C_TOKEN = None
+
+
+def _strip_c_comments(text: str) -> str:
+    """C / C++ source without comments and with runs of white space collapsed (string literals are kept as they are)"""
+    global _C_TOKEN
+    if _C_TOKEN is None:
+        import re
+        _C_TOKEN = re.compile(r'"(?:\\.|[^"\\\n])*"|\'(?:\\.|[^\'\\\n])*\'|//[^\n]*|/\*.*?\*/', re.S)
+    out = _C_TOKEN.sub(lambda m: m.group(0) if m.group(0)[0] in "\"'" else " ", text)
+    return " ".join(out.split())
+
+
 def kernel_source_sha() -> str:
-    """sha256 over the kernel sources (csrc/*.hpp, *.hip, include/*.h): ties a committed counter capture to a build"""
+    """sha256 over the kernel sources (csrc/*.hpp, *.hip, include/*.h) with comments and white space removed: ties a
+    committed counter capture to the code of a build (a reworded comment does not make a capture stale)"""
     import hashlib
     h = hashlib.sha256()
     for d, pat in ((os.path.join(PKG_DIR, "csrc"), (".hpp", ".hip")), (os.path.join(REPO, "include"), (".h",))):
         for name in sorted(os.listdir(d)):
             if name.endswith(pat):
-                with open(os.path.join(d, name), "rb") as fh:
-                    h.update(name.encode() + b"\0" + fh.read())
+                with open(os.path.join(d, name), "r", encoding="utf-8", errors="replace") as fh:
+                    h.update(name.encode() + b"\0" + _strip_c_comments(fh.read()).encode())
     return h.hexdigest()
 
 

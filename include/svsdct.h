@@ -75,9 +75,11 @@ extern "C" {
  *                      exactly as pocketfft does (every quantiser decision is the reference's), predicts each stego
  *                      pixel from the sparse inverse of the coefficient changes, and keeps the prediction only where a
  *                      RIGOROUS per-block bound on the reference's round-trip noise (tools/guard_bound.py: running
- *                      error analysis of every pocketfft operation; BETA = u (17 mean + 39.4 ||block - mean||_2 +
- *                      197 * 1.5 delta)) proves the truncation cannot differ; the 0.3 - 2.5 % of blocks it cannot
- *                      decide (12.5 % of flat blocks at n = 3) are redone exactly.  Applies to n_ac <= 7 and
+ *                      error analysis of every pocketfft operation; BETA = u (17.0 mean + 31.05 ||block - mean||_2 +
+ *                      KD (1.5 delta + 0.01)) + 2^-20, KD = 19.6 for n_ac <= 7, 54.8 for n_ac <= 15) proves the
+ *                      truncation cannot differ; the blocks it cannot decide are redone exactly inside the launch
+ *                      (n_ac <= 7: 8 tests per block, 0.05 - 1.7 % of the blocks, 12.5 % of flat ones at n = 3;
+ *                      n_ac = 8..15: 64 tests with position-dependent bounds, 1.5 - 13 %).  Applies to n_ac <= 15 and
  *                      0.25 <= delta <= 4096; other calls run the SVS_EXACT_POCKETFFT kernels, so the flag is always
  *                      safe to pass and always bit-identical.  Default of the drop-in operator and video pipelines. */
 #define SVS_EXACT_POCKETFFT 1u

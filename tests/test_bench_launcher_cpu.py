@@ -60,3 +60,17 @@ def test_a_rank_does_not_launch_again():
     env = dict(os.environ, RANK="1", WORLD_SIZE="2", LOCAL_RANK="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999")
     res = subprocess.run([sys.executable, "-c", script], env=env, capture_output=True, text=True, timeout=300)
     assert "a rank tried to launch ranks" not in res.stderr and "rank path:" in res.stdout, res.stdout + res.stderr
+
+
+def test_kernel_source_hash_ignores_comments_and_layout_only():
+    """roofline.traffic is reported only when profiles/hbm_traffic.json was captured from this build's kernel CODE: the hash
+    must not move when a comment is reworded, and must move when a token changes."""
+    sys.path.insert(0, REPO)
+    import bench
+    a = 'int f(int x) { /* old words */ return x + 1; }  // tail\nconst char *s = "// kept /* kept */";\n'
+    b = 'int f(int x) {\n    return x + 1;   /* new\n words */\n}\nconst char *s = "// kept /* kept */";'
+    c = a.replace("x + 1", "x + 2")
+    assert bench._strip_c_comments(a) == bench._strip_c_comments(b) != bench._strip_c_comments(c)
+    assert '"// kept /* kept */"' in bench._strip_c_comments(a)
+    h = bench.kernel_source_sha()
+    assert len(h) == 64 and h == bench.kernel_source_sha()
