@@ -13,7 +13,7 @@ import os
 import numpy as np
 import pytest
 
-from testlib import (CONTRACT_POINTS, GUARDED_POINTS, ORIGINAL_COVERS, REPO, case_inputs, emu_embed, emu_extract, exact_tie_mask, golden_bits,
+from testlib import (CONTRACT_POINTS, GUARDED_POINTS, guarded_soak_cases, ORIGINAL_COVERS, REPO, case_inputs, emu_embed, emu_extract, exact_tie_mask, golden_bits,
                      natural_like, sha, single_frame_cases, structured_covers)
 from oracle import qim_dct_oracle as orc
 from svsdct import batch, native, synth
@@ -492,6 +492,19 @@ def test_random_geometries_match_the_cpu_build_of_the_kernel_header():
         assert used_x == ref_used and np.array_equal(stego_x, ref), (it, f, h, w, n_ac, delta)
         packed, n = batch.extract_frames(frames, delta, n_ac, mode="exact")
         assert np.array_equal(np.unpackbits(packed, count=n), orc.batch_extract_bits(frames, delta, n_ac))
+
+
+def test_guarded_mode_random_geometries_steps_and_budgets_equal_the_oracle():
+    """GUARDED over what the structured-content points do not vary (testlib.guarded_soak_cases: shapes, partial waves,
+    budgets ending inside a block, bit offsets, every n <= 15, quantiser steps of all three evaluation kinds inside and outside
+    the guard's delta range, mixed content).  The stego frames must be the oracle's, byte for byte."""
+    for it, frames, delta, n_ac, bits, off, n_bits, cap in guarded_soak_cases():
+        stego, used = batch.embed_frames(frames, delta, n_ac, bits, bit_offset=off, n_bits=n_bits, mode="guarded")
+        ref, ref_used = orc.batch_embed(frames, delta, bits[off:off + n_bits], n_ac)
+        assert used == ref_used == min(n_bits, cap), (it, used, ref_used)
+        assert np.array_equal(stego, ref), (it, frames.shape, n_ac, delta, int((stego != ref).sum()))
+        packed, n = batch.extract_frames(stego, delta, n_ac, mode="guarded")
+        assert np.array_equal(np.unpackbits(packed, count=n), orc.batch_extract_bits(stego, delta, n_ac)), (it, n_ac, delta)
 
 
 def test_idempotent_and_deterministic():

@@ -13,7 +13,7 @@ import numpy as np
 import pytest
 from hypothesis import given, settings, strategies as st
 
-from testlib import (CSRC, GUARDED_POINTS, REPO, case_inputs, emu_embed, sha, single_frame_cases, structured_covers)
+from testlib import (CSRC, GUARDED_POINTS, guarded_soak_cases, REPO, case_inputs, emu_embed, sha, single_frame_cases, structured_covers)
 from oracle import qim_dct_oracle as orc
 from svsdct import synth
 
@@ -159,3 +159,14 @@ def test_guarded_equals_oracle_hypothesis(seed, n_ac, delta, kind):
     got, used = emu_embed(cover, delta, n_ac, bits, exact=4)
     _, ref, ref_used = orc.frame_embed(cover, delta, bits, n_ac)
     assert used == ref_used and np.array_equal(got[0], ref)
+
+
+def test_random_geometries_steps_and_budgets_equal_the_oracle():
+    """CPU twin of the GPU tier's soak (same cases): the guarded dispatch of the kernel header - one-row guard, two-row guard,
+    exact arithmetic above 15 coefficients and outside the delta range - gives the oracle's stego frames byte for byte."""
+    redone = [0, 0]
+    for it, frames, delta, n_ac, bits, off, n_bits, cap in guarded_soak_cases():
+        got, used = emu_embed(frames, delta, n_ac, bits, bit_offset=off, exact=4, replayed=redone)
+        ref, ref_used = orc.batch_embed(frames, delta, bits[off:off + n_bits], n_ac)
+        assert used == ref_used == min(n_bits, cap), (it, used, ref_used)
+        assert np.array_equal(got, ref), (it, frames.shape, n_ac, delta, int((got != ref).sum()))

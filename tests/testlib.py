@@ -185,3 +185,33 @@ def emu_extract(frames, delta, n_ac, exact=False, redone=None):
     if redone is not None:
         redone.append(int(count.value))
     return out
+
+
+def guarded_soak_cases(count=64, seed=77):
+    """Random (frames, delta, n_ac, bits, bit_offset, n_bits) cases for the GUARDED mode: shapes with odd and even block
+    counts per row, partial waves, budgets ending inside a block, bit offsets, every n <= 15 (every eighth case above, where
+    the exact kernels run), quantiser steps of all three evaluation kinds (power of two, float32, not a float32) across the
+    guard's delta range and outside it, frames mixing noise with flat, dark, saturated and smooth areas."""
+    rng = np.random.default_rng(seed)
+    steps = [8, 0.5, 2, 20, 7.5, 13, 0.3, 0.7, 1.1, 100, 1000.5, 4096, 0.25, 0.2, 5000, 3.3]
+    for it in range(count):
+        f = int(rng.integers(1, 5))
+        h, w = 8 * int(rng.integers(1, 14)), 8 * int(rng.integers(1, 36))
+        n_ac = int(rng.integers(1, 16)) if it % 8 else int(rng.integers(16, 64))
+        delta = steps[it % len(steps)]
+        frames = rng.integers(0, 256, (f, h, w), dtype=np.uint8)
+        kind = it % 5
+        if kind == 1:
+            frames[:, : h // 2] = int(rng.integers(0, 256))                 # flat area
+        elif kind == 2:
+            frames //= 32                                                    # dark: clipping at 0
+        elif kind == 3:
+            frames[:] = 255 - frames // 32                                   # bright: clipping at 255
+        elif kind == 4:
+            yy, xx = np.mgrid[0:h, 0:w]
+            frames[:] = np.clip(40 + 0.8 * xx + 0.5 * yy + frames // 64, 0, 255).astype(np.uint8)
+        cap = f * (h // 8) * (w // 8) * min(n_ac, 63)
+        off = int(rng.integers(0, 70))
+        n_bits = cap if it % 3 == 0 else int(rng.integers(0, cap + 9))
+        bits = rng.integers(0, 2, off + n_bits).astype(np.uint8)
+        yield it, frames, delta, n_ac, bits, off, n_bits, cap
