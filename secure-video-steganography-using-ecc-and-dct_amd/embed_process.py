@@ -20,7 +20,7 @@ from config_and_setup import (bitstream_ke_bytes, buat_pasangan_kunci_ecc, buat_
                               serialisasi_kunci_publik_ecc_compressed, setup_kunci_ecc)  # noqa: F401
 from svsdct import batch as _batch
 from svsdct import framing as _framing
-from svsdct.pipeline import FramePipeline
+from svsdct.pipeline import FramePipeline, SlotFeeder, read_ahead
 
 BATCH_FRAMES = int(os.environ.get("SVS_BATCH_FRAMES", "32"))
 PIPELINE_DEPTH = int(os.environ.get("SVS_PIPELINE_DEPTH", "3"))     # batches in flight between decode and encode
@@ -169,49 +169,47 @@ def embed_gambar_ke_video_final(path_video_input, path_gambar_rahasia, path_vide
             if sisa is not None:
                 sisa -= len(frames)
     else:
-        # Overlapped staging: batch k+1 is decoded while batch k is on the GPU (H2D copy, kernel and
-        # D2H copy run asynchronously on the slot's stream) and batch k-1 is encoded; the payload is uploaded once.
+        # Overlapped staging: batch k+1 is decoded (feeder thread) while batch k is on the GPU (H2D copy,
+        # kernel and D2H copy run asynchronously on the slot's stream) and batch k-1 is encoded (this thread); the payload is
+        # uploaded once.
         per_batch = BATCH_FRAMES if carrying is None else max(1, min(BATCH_FRAMES, carrying))
         n_batches = PIPELINE_DEPTH if carrying is None else -(-carrying // per_batch)
         with FramePipeline(out_h, out_w, per_batch, delta_kuantisasi, num_ac_coeffs,
                            depth=max(1, min(PIPELINE_DEPTH, n_batches)), mode=_batch.host_level_mode()) as pipe:
             pipe.set_payload(payload)
-            pending = []                                               # (slot, gray frames, bits expected) in flight
-            sisa, k = carrying, 0
+            rencana = {"sisa": carrying}
 
-            def selesaikan():
-                slot, gray, expect, used = pending.pop(0)
-                if used != expect:
-                    raise RuntimeError(f"embed kernel consumed {used} bits, expected {expect}")
-                tulis(gray, pipe.embed_result(slot))
+            def isi(slot):
+                """decode the next batch straight into the slot's pinned input (feeder thread)"""
+                mau = per_batch if rencana["sisa"] is None else min(per_batch, rencana["sisa"])
+                masukan, n = pipe.input(slot), 0
+                while n < mau:
+                    ok, frame_bgr = cap.read()
+                    if not ok:
+                        break
+                    masukan[n] = cv2.cvtColor(frame_bgr[0:out_h, 0:out_w], cv2.COLOR_BGR2GRAY)
+                    n += 1
+                if rencana["sisa"] is not None:
+                    rencana["sisa"] -= n
+                return n
 
-            while sisa is None or sisa > 0:
-                slot = k % pipe.depth
-                if len(pending) == pipe.depth:
-                    selesaikan()                                       # frees this slot
-                frames = baca(per_batch if sisa is None else min(per_batch, sisa))
-                if not frames:
-                    habis = True
-                    break
-                gray = np.stack(frames)
-                np.copyto(pipe.input(slot)[:len(frames)], gray)
+            def kirim(slot, k, n):
                 offset = k * per_batch * usable
-                used = pipe.submit_embed(slot, len(frames), bit_offset=min(offset, total_bits))
-                pending.append((slot, gray, min(len(frames) * usable, max(0, total_bits - offset)), used))
-                if sisa is not None:
-                    sisa -= len(frames)
-                k += 1
-            while pending:
-                selesaikan()
+                used = pipe.submit_embed(slot, n, bit_offset=min(offset, total_bits))
+                return used, min(n * usable, max(0, total_bits - offset))
+
+            with SlotFeeder(pipe, isi, kirim) as feeder:
+                for slot, k, n, (used, expect) in feeder:
+                    if used != expect:
+                        raise RuntimeError(f"embed kernel consumed {used} bits, expected {expect}")
+                    tulis(pipe.input(slot)[:n], pipe.embed_result(slot))
+                    feeder.release(slot)
     disisipkan = state["disisipkan"]
     selesai = usable > 0 and disisipkan >= total_bits
     if selesai:
         print("    Semua payload (SHA3-ECC-AES) berhasil disisipkan!")
-        while True:                                                    # remaining frames: copied, in colour (:134-139)
-            ok, frame_bgr = cap.read()
-            if not ok:
-                break
-            writer.write(frame_bgr[0:out_h, 0:out_w])
+        for frame_bgr in read_ahead(cap.read):                         # remaining frames: copied, in colour (:134-139);
+            writer.write(frame_bgr[0:out_h, 0:out_w])                  # decoded on a thread while this one encodes
     else:
         print(f"    Warning: Video selesai sebelum semua payload ({total_bits} bits) disisipkan.")
     first_gray, first_stego = state["first"] if state["first"] else (None, None)

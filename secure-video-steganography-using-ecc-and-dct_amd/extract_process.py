@@ -18,7 +18,7 @@ from config_and_setup import (bytes_ke_bitstream, buat_shared_secret_ecdh, dekri
                               hitung_sha3_256, setup_kunci_ecc)  # noqa: F401
 from svsdct import batch as _batch
 from svsdct import framing as _framing
-from svsdct.pipeline import FramePipeline
+from svsdct.pipeline import FramePipeline, SlotFeeder
 
 BATCH_FRAMES = int(os.environ.get("SVS_BATCH_FRAMES", "32"))
 PIPELINE_DEPTH = int(os.environ.get("SVS_PIPELINE_DEPTH", "3"))     # batches in flight between decode and the kernels
@@ -143,42 +143,35 @@ def ekstraksi_gambar_video_final(path_stego_video, path_gambar_output,
                 print(f"    Sisa ciphertext diekstrak sampai frame {frame_num}. "
                       f"Total bit ciphertext terkumpul: {sum(p.size for p in pieces)}")
         else:
-            # overlapped staging: batch k+1 is decoded while batch k is copied to the GPU, extracted and copied back
+            # overlapped staging: batch k+1 is decoded (feeder thread) while batch k is copied to the GPU, extracted and
+            # copied back and the bits of batch k-1 are unpacked here
             per_batch = max(1, min(BATCH_FRAMES, lagi))
             with FramePipeline(h, w, per_batch, delta_kuantisasi, num_ac_coeffs,
                                depth=max(1, min(PIPELINE_DEPTH, -(-lagi // per_batch))),
                                mode=_batch.host_level_mode()) as pipe:
-                pending, k = [], 0
+                rencana = {"lagi": lagi}
 
-                def kumpulkan():
-                    nonlocal frame_num
-                    slot, n_frames = pending.pop(0)
-                    packed, n_bits = pipe.extract_result(slot)
-                    pieces.append(np.unpackbits(packed, count=n_bits))
-                    frame_num += n_frames
-                    print(f"    Sisa ciphertext diekstrak sampai frame {frame_num}. "
-                          f"Total bit ciphertext terkumpul: {sum(p.size for p in pieces)}")
-
-                while lagi > 0:
-                    slot = k % pipe.depth
-                    if len(pending) == pipe.depth:
-                        kumpulkan()
-                    grays = []
-                    while len(grays) < min(per_batch, lagi):
+                def isi(slot):
+                    masukan, n = pipe.input(slot), 0
+                    while n < min(per_batch, rencana["lagi"]):
                         gray = baca_gray()
                         if gray is None:
                             break
-                        grays.append(gray)
-                    if not grays:
-                        print("    Warning: Video selesai sebelum semua ciphertext diekstrak.")
-                        break
-                    np.copyto(pipe.input(slot)[:len(grays)], np.stack(grays))
-                    pipe.submit_extract(slot, len(grays))
-                    pending.append((slot, len(grays)))
-                    lagi -= len(grays)
-                    k += 1
-                while pending:
-                    kumpulkan()
+                        masukan[n] = gray
+                        n += 1
+                    rencana["lagi"] -= n
+                    return n
+
+                with SlotFeeder(pipe, isi, lambda slot, k, n: pipe.submit_extract(slot, n)) as feeder:
+                    for slot, k, n, _ in feeder:
+                        packed, n_bits = pipe.extract_result(slot)
+                        pieces.append(np.unpackbits(packed, count=n_bits))
+                        feeder.release(slot)
+                        frame_num += n
+                        print(f"    Sisa ciphertext diekstrak sampai frame {frame_num}. "
+                              f"Total bit ciphertext terkumpul: {sum(p.size for p in pieces)}")
+                if rencana["lagi"] > 0:                              # the reference warns when a read fails (:177)
+                    print("    Warning: Video selesai sebelum semua ciphertext diekstrak.")
         ct_bits = np.concatenate(pieces)
     if ct_bits.size < butuh:
         print("  Ekstraksi GAGAL: Ciphertext tidak lengkap.")

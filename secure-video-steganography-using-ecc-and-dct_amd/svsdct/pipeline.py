@@ -15,10 +15,17 @@ overlap on the two DMA directions.
             consume(pipe.embed_result(slot))     # stego of batch k - depth (waits for that slot only)
         np.copyto(pipe.input(slot)[:len(frames)], frames)
         pipe.submit_embed(slot, len(frames), bit_offset=k * pipe.batch_capacity)
+
+With a host producer that blocks outside the interpreter lock (cv2 decoding) the loop above still serialises decode and
+encode; `SlotFeeder` moves the producer half (decode into the slot's pinned buffer + submit) to a thread of its own, so
+that decoding, the GPU and the consumer's encoding all run at once, and `read_ahead` does the same for a plain
+decode -> encode copy loop.
 """
 from __future__ import annotations
 
 import ctypes as C
+import queue
+import threading
 
 import numpy as np
 
@@ -46,6 +53,7 @@ class FramePipeline:
             raise ValueError("frame height and width must be multiples of 8")
         native.ensure_device(device)
         self.lib = native.load()
+        self.device = device
         self.h, self.w, self.batch, self.depth = height, width, batch_frames, depth
         self.delta, self.n_ac, self.mode = delta, n_ac, mode
         self.frame_capacity = batch.capacity_bits(1, height, width, n_ac)
@@ -65,6 +73,10 @@ class FramePipeline:
                                     d_bits=_device(self._bits_bytes), frames=0, bits=0))
         self._d_payload = None
         self._payload_bits = 0
+
+    def bind_thread(self) -> None:
+        """Call once on any other thread that is going to use this pipeline (HIP's current device is per thread)."""
+        native.ensure_device(self.device)
 
     # ---- payload (embed) ------------------------------------------------------------------------
     def set_payload(self, bits: np.ndarray) -> None:
@@ -141,3 +153,119 @@ class FramePipeline:
 
     def __exit__(self, *exc):
         self.close()
+
+
+class SlotFeeder:
+    """Producer half of an overlapped frame loop, on a thread of its own.
+
+    The thread takes a free slot, calls `fill(slot)` - which puts up to a batch of frames into `pipe.input(slot)` and returns
+    how many (0 = end of input) -, calls `submit(slot, k, n)` - which enqueues the slot's GPU work (`submit_embed` /
+    `submit_extract` return at once) and returns whatever the consumer wants to know about batch k -, and passes
+    `(slot, k, n, info)` on, in order.  The consumer iterates the feeder, collects the slot's result (`*_result` waits for
+    that slot's stream only), uses it, and hands the slot back with `release(slot)`; only then is it filled again, so
+    `pipe.input(slot)` and the result stay valid for as long as the consumer holds the slot.
+
+        with SlotFeeder(pipe, fill, submit) as feeder:
+            for slot, k, n, info in feeder:
+                consume(pipe.embed_result(slot))
+                feeder.release(slot)
+
+    With `depth` slots, batch k + 1 is decoded while batch k is on the GPU and batch k - 1 is being consumed (encoded):
+    decoders and encoders such as cv2's release the interpreter lock, so the three really run at the same time.
+    An exception on the thread is raised again in the consumer; leaving the `with` block stops the thread."""
+
+    _END = object()
+
+    def __init__(self, pipe, fill, submit):
+        self._free: queue.Queue = queue.Queue()
+        for slot in range(pipe.depth):
+            self._free.put(slot)
+        self._ready: queue.Queue = queue.Queue()
+        self._stop = threading.Event()
+        self._thread = threading.Thread(target=self._run, args=(pipe, fill, submit), name="svs-slot-feeder", daemon=True)
+        self._thread.start()
+
+    def _run(self, pipe, fill, submit):
+        try:
+            bind = getattr(pipe, "bind_thread", None)
+            if bind is not None:
+                bind()
+            k = 0
+            while True:
+                slot = self._free.get()
+                if slot is None or self._stop.is_set():
+                    break
+                n = fill(slot)
+                if n <= 0:
+                    break
+                self._ready.put((slot, k, n, submit(slot, k, n)))
+                k += 1
+            self._ready.put(self._END)
+        except BaseException as exc:       # handed to the consumer
+            self._ready.put(exc)
+
+    def __iter__(self):
+        while True:
+            item = self._ready.get()
+            if item is self._END:
+                return
+            if isinstance(item, BaseException):
+                raise item
+            yield item
+
+    def release(self, slot: int) -> None:
+        self._free.put(slot)
+
+    def close(self) -> None:
+        self._stop.set()
+        self._free.put(None)
+        self._thread.join()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+
+def read_ahead(read, depth: int = 8):
+    """Generator over the frames of `read() -> (ok, frame)` (cv2.VideoCapture.read), decoded up to `depth` frames ahead on a
+    thread: the decoder runs while the consumer does something else with the previous frames (e.g. encodes them)."""
+    frames: queue.Queue = queue.Queue(maxsize=max(1, depth))
+    stop = threading.Event()
+    end = object()
+
+    def put(item):
+        while not stop.is_set():
+            try:
+                frames.put(item, timeout=0.05)
+                return True
+            except queue.Full:
+                pass
+        return False
+
+    def run():
+        try:
+            while not stop.is_set():
+                ok, frame = read()
+                if not ok:
+                    break
+                if not put(frame):
+                    return
+            put(end)
+        except BaseException as exc:
+            put(exc)
+
+    thread = threading.Thread(target=run, name="svs-read-ahead", daemon=True)
+    thread.start()
+    try:
+        while True:
+            item = frames.get()
+            if item is end:
+                return
+            if isinstance(item, BaseException):
+                raise item
+            yield item
+    finally:
+        stop.set()
+        thread.join()

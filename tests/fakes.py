@@ -8,6 +8,7 @@ import types
 
 import numpy as np
 
+WRITE_DELAY = [0.0]   # seconds every VideoWriter.write sleeps (tests of the decode / encode overlap set it)
 VIDEOS = {}      # path -> {"frames": [BGR uint8 arrays], "fps": float, "size": (w, h), "fourcc": int}
 
 
@@ -52,6 +53,9 @@ def make_fake_cv2():
         def write(self, frame):
             w, h = VIDEOS[self.path]["size"]
             assert frame.shape == (h, w, 3) and frame.dtype == np.uint8, frame.shape
+            if WRITE_DELAY[0]:                                      # a slow encoder
+                time.sleep(WRITE_DELAY[0])
+            VIDEOS[self.path].setdefault("write_times", []).append(time.perf_counter())
             VIDEOS[self.path]["frames"].append(frame.copy())
 
         def release(self):
@@ -157,6 +161,9 @@ class EmuFramePipeline:
         self._in = [np.zeros((batch_frames, height, width), np.uint8) for _ in range(depth)]
         self._out = [None] * depth
         self._payload = np.zeros(0, np.uint8)
+
+    def bind_thread(self):
+        pass
 
     def set_payload(self, bits):
         self._payload = np.asarray(bits, np.uint8).copy()
