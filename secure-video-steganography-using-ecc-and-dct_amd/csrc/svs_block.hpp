@@ -960,8 +960,8 @@ SVS_HD void embed_block_exact(uint32_t (&rx)[8], uint32_t (&ry)[8], uint32_t n, 
 // Otherwise the function returns true and the caller redoes the block with the pocketfft-identical arithmetic
 // (embed_block_exact on the host emulation; the 8-lanes-per-block replay inside the kernel, svs_device.hpp).
 // With one coefficient row (n <= 7) the change is the same in all 8 rows of a column, so only 8 values are tested and a
-// noise block (mean 128, sigma 65, delta 8) is flagged with probability 16 * BETA = 2.4 %; smooth content 0.6 %.
-// Constants printed by tools/guard_bound.py (tests/test_guard_bound_cpu.py re-derives them):
+// noise block (mean 128, sigma 65, delta 8: BETA = 1.1e-3) is flagged with probability 16 * BETA = 1.7 %; smooth content 0.5 %.
+// Constants printed by tools/guard_bound.py (tests/test_guarded_mode_cpu.py re-derives them):
 #define SVS_GUARD_KDC 17.0001      // per unit of the mean pixel value
 #define SVS_GUARD_KE 31.05         // per unit of ||X - mean||_2 (the (2 -> 1) norm is at least 30.66: the bound is tight)
 #define SVS_GUARD_KD_U1 19.61      // per unit of 1.5 delta + 0.01, at most 7 modified coefficients (incl. the kernel's own sparse inverse)

@@ -620,7 +620,7 @@ __device__ __forceinline__ uint32_t guard_phase2(GuardEntry *entries, float *til
 // guard sends only structured blocks there), so at U = 2 the kernel is allocated for what its HOT path needs - 72 VGPRs (U = 4: 128) - and the inlined
 // replay spills 12 bytes into scratch where it runs: 300 x 1080p n = 10 0.213 vs 0.223 ms,
 // 600 x 4K 1.637 vs 1.689 ms against the natural allocation of 90 VGPRs (profiles/r03_ab_occupancy.txt).  With one row the
-// replay runs in 95 % of the waves and spills there cost far more than the occupancy gains (1.90 vs 1.71 ms): natural allocation.
+// replay runs in 89 % of the waves and spills there cost far more than the occupancy gains (1.90 vs 1.71 ms): natural allocation.
 #ifndef SVS_U3_MIN_WAVES
 #define SVS_U3_MIN_WAVES 1   // natural allocation (108 VGPRs): 6 waves spill 116 B into the level-2 scan - 1.11 vs 0.79 ms at n = 20
 #endif
