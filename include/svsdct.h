@@ -81,7 +81,9 @@ extern "C" {
  *                      (n_ac <= 7: 8 tests per block, 0.05 - 1.7 % of the blocks, 12.5 % of flat ones at n = 3;
  *                      n_ac = 8..15: 64 tests with position-dependent bounds, 1.5 - 13 %).  Applies to n_ac <= 15 and
  *                      0.25 <= delta <= 4096; other calls run the SVS_EXACT_POCKETFFT kernels, so the flag is always
- *                      safe to pass and always bit-identical.  Default of the drop-in operator and video pipelines. */
+ *                      safe to pass and always bit-identical.  Extraction with this flag runs the FAST kernels (their
+ *                      bits are the reference's for any input, see above) inside the same delta range, the
+ *                      pocketfft-identical kernels outside it.  Default of the drop-in operator and video pipelines. */
 #define SVS_EXACT_POCKETFFT 1u
 #define SVS_EXACT_GUARDED 2u
 

@@ -564,7 +564,13 @@ int svs_extract_dev(const uint8_t *d_gray, const svs_planes *planes, double delt
         const int rows = rows_for(n);
         int rc;
         if (flags & ~(SVS_EXACT_POCKETFFT | SVS_EXACT_GUARDED)) return fail(SVS_ERR_INVALID_ARG, "unknown flags 0x%x", flags);
-        if (flags & SVS_EXACT_GUARDED) flags = SVS_EXACT_POCKETFFT;   // extraction: the pocketfft-identical kernels
+        // GUARDED extraction = the FAST kernels: their bits are the reference's for any input by construction (n <= 7: the
+        // pocketfft-identical forward; n >= 8: a block with a quantiser input inside the PROVEN per-block error bound of a
+        // rounding tie is recomputed with it, tools/guard_bound.py --tie), at 0.86 instead of 1.03 ms per 600 x 4K at n = 10.
+        // Outside the guard's delta range the flag means the pocketfft-identical kernels, as for embedding.
+        if (flags & SVS_EXACT_GUARDED)
+            flags = (delta >= SVS_GUARD_DELTA_MIN && delta <= SVS_GUARD_DELTA_MAX && env_chunk("SVS_GUARDED_OFF", 0) == 0)
+                        ? 0u : SVS_EXACT_POCKETFFT;
         // With one coefficient row (n <= 7) the pocketfft-identical forward transform costs 0.2-3 % (the kernel stays
         // HBM-bound; in-process A/B in profiles/r01_ab_quant_exact.txt), so FAST mode uses it too and extraction is
         // bit-identical to the reference for ANY input frame.  With more rows it costs ~17 % and stays opt-in.

@@ -26,7 +26,8 @@ MAX_AC = 63
 #   "guarded" stego pixels bit-identical to the reference.  n_ac <= 15: the streaming kernel (cheap sparse transform wherever a
 #            rigorous bound on the reference's float32 round-trip noise proves it equals the reference's truncation, the
 #            pocketfft-identical arithmetic inside the same launch for the few blocks where it cannot; 8 tests per block
-#            at n_ac <= 7, 64 at n_ac = 8..15); n_ac >= 16 or delta outside [0.25, 4096]: the "exact" kernels.
+#            at n_ac <= 7, 64 at n_ac = 8..15); n_ac >= 16 or delta outside [0.25, 4096]: the "exact" kernels.  Extraction:
+#            the "fast" kernels (their bits are the reference's for any input).
 #            Default of the NumPy level, the drop-in operator and the video pipelines.
 #   "fast"   n_ac <= 7: the same launch as "guarded".  n_ac >= 8: FMA-factored DCT on the coefficient rows the payload
 #            touches with a per-pixel guard - contract parity (bits exact, PSNR within 0.01 dB).  Default of the
