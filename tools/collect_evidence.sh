@@ -1,0 +1,26 @@
+#!/bin/bash
+# Copy what tools/gpu/r3_evidence.sh left under gpurun_out/ev into profiles/ (run in the build container, where .git is):
+#   tools/collect_evidence.sh r03_c      -> profiles/r03_c_bench.json, ..., and the un-suffixed counter / probe / A/B files
+set -eu
+TAG=${1:?tag, e.g. r03_c}; ROUND=${TAG%%_*}
+cd "$(dirname "$0")/.."
+E=gpurun_out/ev; REV=$(git rev-parse --short HEAD)
+grep '^{' $E/bench.json | tail -1 > profiles/${TAG}_bench.json
+cp $E/kernel_stats.csv profiles/${TAG}_kernel_stats.csv
+grep '^{' $E/rocprof_stats.log | tail -1 > profiles/${TAG}_bench_under_rocprof.json
+if [ -f $E/hbm_traffic.json ]; then
+  sed "s/commit , tag/commit $REV, tag/" $E/hbm_traffic.json > profiles/hbm_traffic.json
+  sed "s/commit , tag/commit $REV, tag/" $E/${ROUND}_pmc_summary.json > profiles/${ROUND}_pmc_summary.json
+fi
+for n in 3 10 63; do [ -f $E/sq_counters_n$n.txt ] && cp $E/sq_counters_n$n.txt profiles/${ROUND}_sq_counters_n$n.txt; done
+[ -f $E/other_configs_bench.jsonl ] && cp $E/other_configs_bench.jsonl profiles/${ROUND}_other_configs_bench.jsonl
+if ls $E/guarded_probe_n*.txt >/dev/null 2>&1; then
+  { for n in 3 1 7 10 15; do [ -f $E/guarded_probe_n$n.txt ] && grep -v amdgpu.ids $E/guarded_probe_n$n.txt; done; } > profiles/${ROUND}_guarded_probe.txt
+fi
+if [ -f $E/tie_fallback_new.txt ]; then
+  { echo "== this build ($REV)"; grep -v amdgpu.ids $E/tie_fallback_new.txt; echo; echo "== round-2 library (lib/variants/libsvsdct_r02.so, rebuilt from 68f741a), same box"; grep -v amdgpu.ids $E/tie_fallback_r02.txt; } > profiles/${ROUND}_tie_fallback_rate.txt
+fi
+[ -f $E/ab_vs_r02.txt ] && { echo "# commit $REV"; cat $E/ab_vs_r02.txt; } > profiles/${ROUND}_ab_vs_r02.txt
+[ -f $E/parity_report.json ] && cp $E/parity_report.json profiles/${ROUND}_parity_report.json
+[ -f $E/pipeline_overlap.json ] && cp $E/pipeline_overlap.json profiles/${ROUND}_pipeline_overlap.json
+echo "profiles/${TAG}_* written at $REV"
