@@ -489,10 +489,23 @@ SVS_HD bool embed_block(uint32_t (&rx)[8], uint32_t (&ry)[8], uint32_t n_rt, uin
             float cn;
             if constexpr (QM == QM_DOUBLE) cn = (float)((double)q * qp.delta_d);
             else cn = (float)q * qp.delta_f;
-            change = ((uint32_t)i < nb) ? cn - c : 0.0f;
+            if constexpr (U >= 3) change = cn - c;   // the budget is applied below, for the one block it concerns
+            else change = ((uint32_t)i < nb) ? cn - c : 0.0f;
             if (k != 4 && k <= SVS_FAST_GENERIC_SPAN) generic = fmaxf(generic, fminf(fabsf(c), fabsf(change)));
         }
         D[u][v] = change;
+    }
+    // Budget (config_and_setup.py:130,132,141): only the block the payload ends in has nb < n - its coefficients past the
+    // budget stay as they are.  With three and more coefficient rows this is kept out of the loop above (a compare and a
+    // select per coefficient for every block of the batch: -2 % at n = 63); on the device it is a branch no lane of an
+    // ordinary wave takes, and that block is always scanned (level 2).  The two-row kernel is register-allocated for its hot
+    // path (svs_device.hpp, SVS_U2_MIN_WAVES) and the extra block pushes 36 more bytes of it into scratch (2.12 vs 1.64 ms
+    // at n = 10): it keeps the select.
+    if constexpr (U >= 3) if (nb < n) {
+#pragma unroll
+        for (int k = 1; k < 8 * U; ++k)
+            if ((uint32_t)(k - 1) >= nb) D[k >> 3][k & 7] = 0.0f;
+        generic = 0.0f;
     }
 
     // inverse transform of the change: horizontal on the U rows, then vertical per column with
@@ -1104,10 +1117,19 @@ SVS_HD bool embed_block_guarded2(uint32_t (&rx)[8], uint32_t (&ry)[8], uint32_t 
             float cn;
             if constexpr (QM == QM_DOUBLE) cn = (float)((double)q * qp.delta_d);
             else cn = (float)q * qp.delta_f;
-            change = ((uint32_t)i < nb) ? cn - c : 0.0f;
+            change = cn - c;   // the budget is applied below, for the one block it concerns
         }
         if (k < 8) D0[k] = change;
         else D1[k - 8] = change;
+    }
+    if (nb < n) {   // the block the payload ends in (see embed_block): coefficients past the budget stay as they are
+#pragma unroll
+        for (int k = 1; k < 16; ++k) {
+            if ((uint32_t)(k - 1) >= nb) {
+                if (k < 8) D0[k] = 0.0f;
+                else D1[k - 8] = 0.0f;
+            }
+        }
     }
     float P0[8], P1[8];
     idct8<8, true>(D0, P0);
