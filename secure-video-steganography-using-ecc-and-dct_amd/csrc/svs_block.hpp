@@ -399,6 +399,10 @@ SVS_HD int quant_index(float c, const QimParams &qp) {
 }
 
 // reference form of the above, used by the tests to validate the shortcut
+// q with its parity forced to the payload bit by +1 (bit 1, q even) or -1 (bit 0, q odd) - config_and_setup.py:150-155:
+// `q % 2` of a negative q is 0 or 1 in python, which is the low bit of the two's complement, so q + bit - (q & 1) is q with
+// its low bit replaced by the bit: one v_bfi_b32 instead of and / subtract / add.
+SVS_HD int force_parity(int q, int bit) { return (q & ~1) | bit; }
 SVS_HD int quant_index_by_division(float c, float delta_f) { return (int)rintf(c / delta_f); }
 
 // 64 stream bits starting at stream bit s of an MSB-first packed buffer viewed as dwords
@@ -485,7 +489,7 @@ SVS_HD bool embed_block(uint32_t (&rx)[8], uint32_t (&ry)[8], uint32_t n_rt, uin
             const int bit = (int)window_bit(hi, lo, i);
             const float c = D[u][v];
             int q = quant_index<QM>(c, qp);
-            q += bit - (q & 1);  // parity of a negative q is non-negative in python (:150)
+            q = force_parity(q, bit);
             float cn;
             if constexpr (QM == QM_DOUBLE) cn = (float)((double)q * qp.delta_d);
             else cn = (float)q * qp.delta_f;
@@ -919,7 +923,7 @@ SVS_HD void embed_block_exact(uint32_t (&rx)[8], uint32_t (&ry)[8], uint32_t n, 
             const int bit = (int)window_bit(hi, lo, i);
             const float c = D2[k >> 4][k & 7][(k >> 3) & 1];
             int q = quant_index<QM>(c, qp);
-            q += bit - (q & 1);
+            q = force_parity(q, bit);
             float cn;
             if constexpr (QM == QM_DOUBLE) cn = (float)((double)q * qp.delta_d);
             else cn = (float)q * qp.delta_f;
@@ -1022,7 +1026,7 @@ SVS_HD bool guard_decide(const uint32_t (&rx)[8], const uint32_t (&ry)[8], uint3
             const int bit = (int)window_bit(hi, lo, i);
             const float c = D[k];
             int q = quant_index<QM>(c, qp);
-            q += bit - (q & 1);
+            q = force_parity(q, bit);
             float cn;
             if constexpr (QM == QM_DOUBLE) cn = (float)((double)q * qp.delta_d);
             else cn = (float)q * qp.delta_f;
@@ -1113,7 +1117,7 @@ SVS_HD bool embed_block_guarded2(uint32_t (&rx)[8], uint32_t (&ry)[8], uint32_t 
             const int bit = (int)window_bit(hi, lo, i);
             const float c = k < 8 ? D0[k] : D1[k - 8];
             int q = quant_index<QM>(c, qp);
-            q += bit - (q & 1);
+            q = force_parity(q, bit);
             float cn;
             if constexpr (QM == QM_DOUBLE) cn = (float)((double)q * qp.delta_d);
             else cn = (float)q * qp.delta_f;
@@ -1224,7 +1228,7 @@ SVS_HD void embed_block_exact_pair(uint32_t (&ax)[8], uint32_t (&ay)[8], uint32_
                 const int bit = (int)window_bit(which ? hi_b : hi_a, which ? lo_b : lo_a, i);
                 const float c = D[k >> 3][k & 7][which];
                 int q = quant_index<QM>(c, qp);
-                q += bit - (q & 1);
+                q = force_parity(q, bit);
                 float cn;
                 if constexpr (QM == QM_DOUBLE) cn = (float)((double)q * qp.delta_d);
                 else cn = (float)q * qp.delta_f;

@@ -519,7 +519,7 @@ __device__ __forceinline__ void guard_replay8(GuardEntry *e, float *t, uint32_t 
             const int bit = (int)window_bit(hi, lo, i);
             const float c = a[u];
             int q = quant_index<QM>(c, qp);
-            q += bit - (q & 1);
+            q = force_parity(q, bit);
             float cn;
             if constexpr (QM == QM_DOUBLE) cn = (float)((double)q * qp.delta_d);
             else cn = (float)q * qp.delta_f;
