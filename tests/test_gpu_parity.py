@@ -610,6 +610,42 @@ def test_pitched_planes_in_place_and_device_helpers():
     assert np.array_equal(sse.astype(np.int64), want_sse)
 
 
+def test_pitched_planes_in_place_with_two_coefficient_rows():
+    """The same pitched, in-place device-pointer call with n = 10 / 13: GUARDED (the rigorous two-row kernel) must give the
+    oracle's frames and FAST what the CPU build of the header gives; padding bytes stay untouched; also with an odd and an even
+    number of blocks per row (one / the 16-byte path is not taken at two rows, but the tile mapping differs)."""
+    lib = native.load()
+    for (f, h, w, n_ac, delta, row_pitch) in [(3, 40, 72, 10, 8, 128), (2, 48, 96, 13, 20, 96), (2, 16, 64, 10, 7.5, 80)]:
+        frame_pitch = row_pitch * h + 64
+        planes = Planes(f, h, w, 0, row_pitch, frame_pitch)
+        span = f * frame_pitch
+        want = synth.synthetic_frames(f, h, w, seed=5, first_frame=2)
+        want[0, :16, :24] = 77                                            # some flat blocks
+        cap = batch.capacity_bits(f, h, w, n_ac)
+        bits = synth.synthetic_bits(cap - 37, seed=6)                      # ends inside the last frame
+        packed = batch.pack_bits(bits)
+        d_bits = _Dev(packed.size + 8)
+        d_bits.put(np.concatenate([packed, np.zeros(8, np.uint8)]))
+        for mode in ("guarded", "fast"):
+            host = np.full(span, 0xAB, np.uint8)
+            for k in range(f):
+                host[k * frame_pitch:k * frame_pitch + h * row_pitch].reshape(h, row_pitch)[:, :w] = want[k]
+            d_frames = _Dev(span)
+            d_frames.put(host)
+            used = batch.embed_device(d_frames.ptr, d_frames.ptr, planes, delta, n_ac, d_bits.ptr, 0, bits.size, mode=mode)
+            assert used == bits.size
+            after = d_frames.get()
+            stego = np.stack([after[k * frame_pitch:k * frame_pitch + h * row_pitch].reshape(h, row_pitch)[:, :w]
+                              for k in range(f)])
+            ref = orc.batch_embed(want, delta, bits, n_ac)[0] if mode == "guarded" else emu_embed(want, delta, n_ac, bits)[0]
+            assert np.array_equal(stego, ref), (mode, f, h, w, n_ac, delta, int((stego != ref).sum()))
+            mask = np.ones(span, bool)
+            for k in range(f):
+                for y in range(h):
+                    mask[k * frame_pitch + y * row_pitch:k * frame_pitch + y * row_pitch + w] = False
+            assert np.all(after[mask] == 0xAB), (mode, "padding written")
+
+
 def test_device_psnr_and_ssim_evaluators():
     """SURVEY 8(f) rank 3: per-frame PSNR / SSIM on device against the CPU restatements (oracle/metrics_oracle.py;
     SSIM restates skimage's algorithm - skimage itself is not installed, so that leg is parity-unpinned)."""
