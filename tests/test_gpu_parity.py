@@ -696,12 +696,12 @@ def test_device_colour_conversions():
         native.SVS_ERR_INVALID_ARG
 
 
-@pytest.mark.parametrize("mode", ["exact", "fast"])
+@pytest.mark.parametrize("mode", ["exact", "fast", "guarded"])
 def test_fused_colour_embed_equals_convert_embed_convert(mode):
     """SURVEY 8(f) rank 2 ("fused read of 3 B/px"): BGR in -> stego BGR out in one kernel must equal
     cvtColor -> operator -> cvtColor (embed_process.py:117-127) done step by step: same gray reference, same stego
     planes (replicated into B, G, R), same bit count; and extraction straight from BGR frames equals extraction
-    from their gray planes.  In exact mode the stego planes are also the oracle's, pixel for pixel."""
+    from their gray planes.  In exact and guarded mode the stego planes are also the oracle's, pixel for pixel."""
     rng = np.random.default_rng(17)
     for (f, h, w, n_ac, delta, short) in ((2, 24, 40, 3, 8, 0), (3, 64, 128, 10, 12.5, 37), (1, 8, 8, 63, 5, 0),
                                           (2, 16, 24, 20, 0.3, 11), (1, 32, 32, 7, 16, 1000000)):
@@ -715,7 +715,7 @@ def test_fused_colour_embed_equals_convert_embed_convert(mode):
         assert used == want_used
         assert np.array_equal(got_gray, gray)
         assert np.array_equal(got_bgr, np.repeat(want_stego[..., None], 3, axis=3)), (f, h, w, n_ac, delta)
-        if mode == "exact":
+        if mode in ("exact", "guarded"):
             ref_stego, ref_used = orc.batch_embed(gray, delta, payload, n_ac)
             assert ref_used == used and np.array_equal(got_bgr[..., 1], ref_stego)
         for src in (got_bgr, bgr):                                      # stego frames and never-embedded frames
