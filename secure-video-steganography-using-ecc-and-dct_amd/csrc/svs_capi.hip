@@ -765,13 +765,33 @@ int svs_embed_bgr_dev(const uint8_t *d_bgr_in, int64_t in_row_pitch, int64_t in_
     const bool in_range = delta >= SVS_GUARD_DELTA_MIN && delta <= SVS_GUARD_DELTA_MAX;
     const bool streaming = use > 0 && in_range && !(flags & SVS_EXACT_POCKETFFT) && (rows_n == 1 || !(flags & SVS_EXACT_GUARDED)) &&
                            rows_n <= (int)env_chunk("SVS_FAST_MAX_ROWS", 8);
-    const bool exact = !streaming && (use > 0 || n_bits > 0);
+    // GUARDED with two coefficient rows: the streaming arithmetic with the rigorous per-pixel guard, as in svs_embed_dev
+    const bool guarded2 = use > 0 && in_range && (flags & SVS_EXACT_GUARDED) && !(flags & SVS_EXACT_POCKETFFT) && rows_n == 2 &&
+                          env_chunk("SVS_GUARDED2_OFF", 0) == 0;
+    const bool exact = !streaming && !guarded2 && (use > 0 || n_bits > 0);
     svs::QimParams qp;
     const int qm = make_qim(use == 0 ? 1.0 : delta, &qp);
     if (streaming && rows_n == 1) svs::make_guard(delta, 1, &qp);
+    if (guarded2) svs::make_guard(delta, 2, &qp);
     g.xcd_chunk = env_chunk("SVS_EMBED_XCD_CHUNK", kEighth);
     const hipStream_t st = (hipStream_t)stream;
     const uint32_t *bw = reinterpret_cast<const uint32_t *>(d_bits_packed);
+    if (guarded2) {
+        const uint64_t w64 = ((bit_offset + use + 7) / 8 + 3) / 4;
+        if (w64 >= (1ull << 32)) return fail(SVS_ERR_INVALID_ARG, "payload too large for one call");
+        const dim3 grid((uint32_t)((total + SVS_WG - 1) / SVS_WG));
+        const uint32_t lds_pad = lds_pad_for(env_chunk("SVS_EMBED_BGR_WG_PER_CU", 0), 16384);
+#define SVS_GO2(QM)                                                                                                          \
+    hipLaunchKernelGGL((svs::embed_bgr_kernel<2, QM, false, true>), grid, dim3(SVS_WG), lds_pad, st, d_bgr_in, d_bgr_out,    \
+                       d_gray_ref, g, c, qp, bw, bit_offset, use, (uint32_t)w64)
+        if (qm == svs::QM_DOUBLE) SVS_GO2(svs::QM_DOUBLE);
+        else if (qm == svs::QM_POW2) SVS_GO2(svs::QM_POW2);
+        else SVS_GO2(svs::QM_F32);
+#undef SVS_GO2
+        SVS_HIP(hipGetLastError());
+        if (n_embedded) *n_embedded = use;
+        return SVS_OK;
+    }
     uint64_t kernel_bits = use;
     uint32_t words = 0;
     if (use == 0) {

@@ -1020,7 +1020,7 @@ __global__ __launch_bounds__(SVS_WG) void gray_to_bgr_kernel(const uint8_t *__re
 // bytes per row, then the wave writes the BGR row as 192 consecutive 8-byte units - unit u = bytes [8*(u%3), +8) of the
 // 24-byte row of the wave's block u/3 - so every store instruction covers 512 contiguous bytes instead of 8 bytes in
 // every 24.
-template <int U, int QM, bool EXACT>
+template <int U, int QM, bool EXACT, bool RIG = false>   // RIG: two rows with the rigorous per-pixel guard (GUARDED, n = 8..15)
 __global__ __launch_bounds__(SVS_WG) void embed_bgr_kernel(const uint8_t *bgr_in,   // may alias bgr_out
                                                         uint8_t *bgr_out, uint8_t *__restrict__ gray_ref,
                                                         const Geometry g, const ColourParams c, const QimParams qp,
@@ -1056,7 +1056,7 @@ __global__ __launch_bounds__(SVS_WG) void embed_bgr_kernel(const uint8_t *bgr_in
                 payload_window(bits, n_words, bit_offset + first, hi, lo);
                 embed_block_exact<8, QM>(ax, ay, n, block_budget(first, n_bits, n), hi, lo, qp);
             } else {
-                und = guard_phase1<U, QM, 0>(ax, ay, n, first, qp, bits, bit_offset, n_bits, n_words);
+                und = guard_phase1<U, QM, 0, RIG>(ax, ay, n, first, qp, bits, bit_offset, n_bits, n_words);
             }
         }
     }

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Bandwidth of the kernels around the operator (colour plumbing, metrics) on device-resident 4K batches."""
+"""Bandwidth of the kernels around the operator (colour plumbing, metrics) on device-resident 4K batches.
+usage: python tools/aux_rates.py [n_ac=3] [delta=8]"""
 import ctypes as C, os, sys
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(REPO, "secure-video-steganography-using-ecc-and-dct_amd"))
@@ -34,12 +35,14 @@ timed("frame_ssim", lambda: native.check(lib.svs_frame_ssim_dev(gray.data_ptr(),
 
 # fused colour path vs the three-step chain (convert, embed, convert) on the same frames
 from svsdct import batch
-n_ac, delta = 3, 8.0
+n_ac = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+delta = float(sys.argv[2]) if len(sys.argv) > 2 else 8.0
+print(f"-- fused colour path, n = {n_ac}, delta = {delta:g}")
 cap = batch.capacity_bits(F, H, W, n_ac)
 bits = torch.empty((cap + 7) // 8 + 8, dtype=torch.uint8, device=dev)
 lib.svs_fill_bits_dev(bits.data_ptr(), cap, 5, 0, st)
 out_bits = torch.empty_like(bits)
-for mode in ("fast", "exact"):
+for mode in ("fast", "guarded", "exact"):
     def chain():
         native.check(lib.svs_bgr_to_gray_dev(bgr.data_ptr(), 3 * W, 3 * W * H, gray.data_ptr(), C.byref(planes), None, st), "x")
         batch.embed_device(gray.data_ptr(), gray2.data_ptr(), planes, delta, n_ac, bits.data_ptr(), 0, cap, st, mode=mode)
