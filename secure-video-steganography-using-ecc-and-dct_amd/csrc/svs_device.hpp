@@ -544,9 +544,11 @@ __device__ __forceinline__ void guard_replay8(GuardEntry *e, float *t, uint32_t 
 template <int U, int QM, int NFIX, bool RIG = false>
 __device__ __forceinline__ bool guard_phase1(uint32_t (&ax)[8], uint32_t (&ay)[8], uint32_t n, uint64_t first,
                                              const QimParams &qp, const uint32_t *__restrict__ bits,
-                                             uint64_t bit_offset, uint64_t n_bits, uint32_t n_words) {
+                                             uint64_t bit_offset, uint64_t n_bits, uint32_t n_words,
+                                             uint32_t *keep_hi = nullptr) {
     uint32_t hi, lo;
     payload_window(bits, n_words, bit_offset + first, hi, lo);
+    if (keep_hi) *keep_hi = hi;
     const uint32_t nb = block_budget(first, n_bits, n);
     if constexpr (U == 1) return embed_block_guarded<QM>(ax, ay, n, nb, hi, lo, qp);
     else if constexpr (U == 2 && RIG) return embed_block_guarded2<QM>(ax, ay, n, nb, hi, lo, qp);   // GUARDED, n = 8..15
@@ -564,11 +566,12 @@ struct GuardPayload {
 // still hold the ORIGINAL pixels, first_a / first_b are their first stream bits) through the worklist `entries` (CAP entries)
 // and the transposition tile `tile` (8 * SVS_GUARD_TILE floats), both private to the wave.  On return the rows of undecided
 // blocks hold the exact stego pixels.  Returns the number of blocks redone.
-template <int QM, bool TWO, int CAP = SVS_GUARD_CAP>
+template <int QM, bool TWO, int CAP = SVS_GUARD_CAP, bool KEPT = false>
 __device__ __forceinline__ uint32_t guard_phase2(GuardEntry *entries, float *tile, uint32_t lane, uint32_t n,
                                                  const QimParams &qp, const GuardPayload &pl,
                                                  bool und_a, uint64_t first_a, uint32_t (&ax)[8], uint32_t (&ay)[8],
-                                                 bool und_b, uint64_t first_b, uint32_t (&bx)[8], uint32_t (&by)[8]) {
+                                                 bool und_b, uint64_t first_b, uint32_t (&bx)[8], uint32_t (&by)[8],
+                                                 uint32_t hi_a = 0, uint32_t hi_b = 0) {
     const uint64_t mask_a = __ballot(und_a);
     const uint64_t mask_b = TWO ? __ballot(und_b) : 0ull;
     if ((mask_a | mask_b) == 0) return 0;   // wave-uniform: the common case costs two ballots
@@ -583,7 +586,8 @@ __device__ __forceinline__ uint32_t guard_phase2(GuardEntry *entries, float *til
 #pragma unroll
             for (int r = 0; r < 8; ++r) { e->px[2 * r] = ax[r]; e->px[2 * r + 1] = ay[r]; }
             uint32_t hi, lo;
-            payload_window(pl.bits, pl.n_words, pl.bit_offset + first_a, hi, lo);
+            if constexpr (KEPT) { hi = hi_a; lo = 0; }   // n <= 15: the window's first word, still in a register from phase 1
+            else payload_window(pl.bits, pl.n_words, pl.bit_offset + first_a, hi, lo);
             e->hi = hi; e->lo = lo; e->nb = block_budget(first_a, pl.n_bits, n);
         }
         if (mine_b) {
@@ -591,7 +595,8 @@ __device__ __forceinline__ uint32_t guard_phase2(GuardEntry *entries, float *til
 #pragma unroll
             for (int r = 0; r < 8; ++r) { e->px[2 * r] = bx[r]; e->px[2 * r + 1] = by[r]; }
             uint32_t hi, lo;
-            payload_window(pl.bits, pl.n_words, pl.bit_offset + first_b, hi, lo);
+            if constexpr (KEPT) { hi = hi_b; lo = 0; }
+            else payload_window(pl.bits, pl.n_words, pl.bit_offset + first_b, hi, lo);
             e->hi = hi; e->lo = lo; e->nb = block_budget(first_b, pl.n_bits, n);
         }
         wave_lds_fence();
@@ -627,6 +632,9 @@ __device__ __forceinline__ uint32_t guard_phase2(GuardEntry *entries, float *til
 #ifndef SVS_U2_MIN_WAVES
 #define SVS_U2_MIN_WAVES 7
 #endif
+#ifndef SVS_KEEP_WINDOW
+#define SVS_KEEP_WINDOW 1
+#endif
 template <int U>
 constexpr int kEmbedMinWaves = U == 2 ? SVS_U2_MIN_WAVES : U == 3 ? SVS_U3_MIN_WAVES : U == 4 ? 4 : 1;
 // index for __launch_bounds__ below (a macro argument cannot hold the comma of a second template argument): the rigorous
@@ -646,6 +654,11 @@ __global__ __launch_bounds__(SVS_WG, kEmbedMinWavesRig<U + (RIG ? 100 : 0)>) voi
     const uint32_t gblock = (tile_id(g.xcd_chunk) * (uint32_t)SVS_WG + threadIdx.x) * BPL;
     const uint32_t n = g.n_ac;
     bool und_a = false, und_b = false, write = false;
+    // n <= 15 (one row; two rows with the rigorous guard, where every wave replays): the payload window of a block is its first
+    // word - kept in a register from phase 1, because re-reading it for the worklist is a global load in the life of every
+    // wave that replays (one-row kernel: 1.58 instead of 1.73 ms per 600 x 4K, and 93 instead of 100 VGPRs)
+    constexpr bool KEPT = (U == 1 || (U == 2 && RIG)) && SVS_KEEP_WINDOW;
+    uint32_t hi_a = 0, hi_b = 0;
     typename RowVec<BPL>::type v[8];
     uint32_t ax[8], ay[8], bx[8], by[8];
     int64_t off = 0;
@@ -661,16 +674,17 @@ __global__ __launch_bounds__(SVS_WG, kEmbedMinWavesRig<U + (RIG ? 100 : 0)>) voi
         write = stego != gray;                         // past the budget: byte-identical copy (the reference's loops `break`, :130,:132)
         if (first < n_bits) {
             write = true;
-            und_a = guard_phase1<U, QM, NFIX, RIG>(ax, ay, n, first, qp, bits, bit_offset, n_bits, n_words);
+            und_a = guard_phase1<U, QM, NFIX, RIG>(ax, ay, n, first, qp, bits, bit_offset, n_bits, n_words, KEPT ? &hi_a : nullptr);
             if constexpr (BPL == 2) {   // a budget of 0 (only the lane the payload ends in can see it) leaves block B as it is
-                if (first + n < n_bits) und_b = guard_phase1<U, QM, NFIX, RIG>(bx, by, n, first + n, qp, bits, bit_offset, n_bits, n_words);
+                if (first + n < n_bits)
+                    und_b = guard_phase1<U, QM, NFIX, RIG>(bx, by, n, first + n, qp, bits, bit_offset, n_bits, n_words, KEPT ? &hi_b : nullptr);
             }
         }
     }
     const GuardPayload pl{bits, bit_offset, n_bits, n_words};
     const uint64_t first_a = (uint64_t)gblock * n;
-    const uint32_t redone = guard_phase2<QM, BPL == 2, CAP>(&entries[wave][0], &tiles[wave][0], lane, n, qp, pl, und_a, first_a, ax, ay,
-                                                            und_b, first_a + n, bx, by);
+    const uint32_t redone = guard_phase2<QM, BPL == 2, CAP, KEPT>(&entries[wave][0], &tiles[wave][0], lane, n, qp, pl, und_a, first_a, ax, ay,
+                                                                  und_b, first_a + n, bx, by, hi_a, hi_b);
     if (replay_counter != nullptr && redone != 0 && lane == 0) atomicAdd(replay_counter, (unsigned long long)redone);
     if (write) {
 #pragma unroll
@@ -1039,6 +1053,8 @@ __global__ __launch_bounds__(SVS_WG) void embed_bgr_kernel(const uint8_t *bgr_in
     // neutral in EXACT mode; all eight rows at once cost 100+ VGPRs and gained 1 % (profiles/r01_aux_kernel_rates.txt)
     wave_load_gray_halves(bgr_in, g, c, gblock - lane, lane, &lds_tile[wave][0][0], ax, ay);
     bool und = false;
+    constexpr bool KEPT = !EXACT && (U == 1 || (U == 2 && RIG)) && SVS_KEEP_WINDOW;   // see embed_kernel
+    uint32_t hi_kept = 0;
     if (live) {
         if (gray_ref != nullptr) {  // the operator's first return value: the gray frame before embedding
             uint8_t *ref = gray_ref + block_offset(gblock, g);
@@ -1056,7 +1072,7 @@ __global__ __launch_bounds__(SVS_WG) void embed_bgr_kernel(const uint8_t *bgr_in
                 payload_window(bits, n_words, bit_offset + first, hi, lo);
                 embed_block_exact<8, QM>(ax, ay, n, block_budget(first, n_bits, n), hi, lo, qp);
             } else {
-                und = guard_phase1<U, QM, 0, RIG>(ax, ay, n, first, qp, bits, bit_offset, n_bits, n_words);
+                und = guard_phase1<U, QM, 0, RIG>(ax, ay, n, first, qp, bits, bit_offset, n_bits, n_words, KEPT ? &hi_kept : nullptr);
             }
         }
     }
@@ -1065,7 +1081,7 @@ __global__ __launch_bounds__(SVS_WG) void embed_bgr_kernel(const uint8_t *bgr_in
         float *t = reinterpret_cast<float *>(entries + 16);
         const GuardPayload pl{bits, bit_offset, n_bits, n_words};
         const uint64_t first = (uint64_t)gblock * g.n_ac;
-        guard_phase2<QM, false, 16>(entries, t, lane, g.n_ac, qp, pl, und, first, ax, ay, false, first, ax, ay);
+        guard_phase2<QM, false, 16, KEPT>(entries, t, lane, g.n_ac, qp, pl, und, first, ax, ay, false, first, ax, ay, hi_kept, 0u);
     }
     wave_store_gray_as_bgr(&lds_tile[wave][0][0], lane, gblock, live, ax, ay, bgr_out, g, c);
 }
