@@ -45,8 +45,8 @@ def parse_args():
                          "--height 1080 --width 1920 --n-ac 10 for BASELINE configs[3], --total-frames 1200 --height 4320 "
                          "--width 7680 for configs[4]")
     ap.add_argument("--mode", default=None, choices=["fast", "guarded", "exact"],
-                    help="transform mode of the timed embed / extract (default: fast, the device-level default; at "
-                         "n_ac <= 7 fast and guarded are the same launch and bit-identical to the reference)")
+                    help="transform mode of the timed embed / extract (default: guarded - what the drop-in operator and the "
+                         "video pipelines run: bit-identical to the reference; at n_ac <= 15 fast is the same launch)")
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--width", type=int, default=3840)
     ap.add_argument("--n-ac", type=int, default=3)
@@ -211,7 +211,7 @@ def main():
             raise SystemExit(f"--total-frames {args.total_frames} leaves rank {rank} of {world} without frames")
     else:                            # weak scaling: every rank runs the N = 1 batch on its own frames
         first_frame, F = rank * args.frames, args.frames
-    mode = args.mode or os.environ.get("SVS_DCT_MODE") or "fast"
+    mode = args.mode or os.environ.get("SVS_DCT_MODE") or "guarded"      # the product default (svsdct.batch, drop-in modules)
     planes = Planes.contiguous(F, H, W)
     cap = batch.capacity_bits(F, H, W, n_ac)
     nbytes = (cap + 7) // 8
@@ -323,6 +323,9 @@ def main():
                  "sse")
     torch.cuda.synchronize()
     bit_errors = int(cnt.item())
+    gpu_sample_packed = None
+    if rank == 0 and world == 1 and args.cpu_frames > 0:     # the timed extract's bits of the frames the oracle will redo below
+        gpu_sample_packed = extracted[: (min(args.cpu_frames, F) * (cap // F) + 7) // 8].clone()
     if use_dist:
         t = torch.tensor([bit_errors], dtype=torch.int64, device=cdev)
         dist.all_reduce(t)
@@ -388,8 +391,8 @@ def main():
                                    f"({per_frame_bits} bits per frame), gray planes resident in HBM",
                        "frames_per_gpu": [c for _, c in shares] if args.total_frames > 0 else F,
                        "total_frames": sum(c for _, c in shares), "height": H, "width": W, "n_ac": n_ac, "delta": delta,
-                       "mode": mode + (" (n_ac <= 7: the same launch as guarded - stego pixels bit-identical to the reference)"
-                                       if mode == "fast" and n_ac <= 7 else ""),
+                       "mode": mode + (" (n_ac <= 15: the same launch as guarded - stego pixels bit-identical to the reference)"
+                                       if mode == "fast" and n_ac <= 15 else ""),
                        "sharding": "frames" if world > 1 else "none",
                        "collective": ("gloo gather of packed bits through host memory (rehearsal)" if args.rehearse_gloo else
                                       "rccl gather of packed bits") if use_dist else "none"},
@@ -405,7 +408,8 @@ def main():
                         "note": "asynchronous: the gather of step k runs beside the kernels of step k + 1; the wait is what "
                                 "is left when its buffer is needed again (and at the end of the timed region)"}
                        if use_dist else None),
-            "roofline": {"bound": "hbm", "kernel": "embed_kernel (one launch: cheap arithmetic + in-kernel exact replay of undecided blocks)",
+            "roofline": {"bound": "hbm", "kernel": ("embed_exact_kernel (lane-per-block pocketfft arithmetic)" if mode == "exact" or (mode == "guarded" and n_ac > 15)
+                                                    else "embed_kernel (one launch: cheap arithmetic + in-kernel exact replay of undecided blocks)"),
                          "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "algorithmic_bytes_per_launch": embed_bytes,
@@ -481,8 +485,11 @@ def main():
                              mode="fast")
         torch.cuda.synchronize()
         got_bits = np.unpackbits(extracted[: (m * per + 7) // 8].cpu().numpy(), count=m * per)
+        gpu_sample_bits = np.unpackbits(gpu_sample_packed.cpu().numpy(), count=m * per)   # what the timed extract returned
         result["parity_sample"] = {
             "frames": m,
+            "gpu_round_trip_bit_errors_on_sample": int((gpu_sample_bits != bits).sum()),
+            "oracle_round_trip_bit_errors_on_sample": int((ref_bits != bits).sum()),
             "gpu_extract_of_reference_stego_bit_mismatches": int((got_bits != ref_bits).sum()),
             "bits_compared": int(m * per),
             "oracle_extract_of_gpu_stego_equals_payload": bool(np.array_equal(
@@ -497,8 +504,19 @@ def main():
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
-    if rank == 0 and bit_errors != 0 and delta >= 8:
-        raise SystemExit("payload bit errors in the round trip")
+    # Exit code: the round trip is WRONG when it loses payload bits the reference itself would not lose.  The reference is
+    # not error-free everywhere (delta = 4: 1.6 % BER on any input; large n with clipping pixels), so the rule is
+    # parity with the oracle on the sample both ran, not "zero" (VERDICT r03 weak #9).
+    if rank == 0 and result is not None:
+        ps = result.get("parity_sample")
+        if ps is not None:
+            if ps["gpu_round_trip_bit_errors_on_sample"] != ps["oracle_round_trip_bit_errors_on_sample"] or \
+               ps["gpu_extract_of_reference_stego_bit_mismatches"] != 0:
+                raise SystemExit("payload bit errors in the round trip differ from the oracle's on the same frames")
+        elif bit_errors != 0 and delta >= 8 and n_ac <= 7:
+            # no CPU sample in this run (--cpu-frames 0 / N > 1): the synthetic frames stay inside [16, 240) and 3 * 1.5 * delta
+            # * 0.1734 <= 12.5 for delta <= 16, so nothing can clip and delta >= 8 is provably error-free
+            raise SystemExit("payload bit errors in the round trip")
 
 
 if __name__ == "__main__":

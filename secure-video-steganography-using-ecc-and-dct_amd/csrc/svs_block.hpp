@@ -215,10 +215,6 @@ SVS_HD void store_row_trunc(float p0, float p1, float p2, float p3, float p4, fl
 #endif
 }
 
-#ifndef SVS_FLOOR_STORE
-#define SVS_FLOOR_STORE 0  // 1: explicit floor + add + store for every U (experiment / A-B)
-#endif
-
 // Forward transform of the coefficient rows u < U of one block.
 // D[u][v] = sum_y sum_x a(u)a(v) p[y][x] cos((2y+1)u pi/16) cos((2x+1)v pi/16)
 // (vertical axis first, as the reference does: axis=0 then axis=1, config_and_setup.py:135).
@@ -439,12 +435,21 @@ SVS_HD float fract_f32(float x) {
     return f < 1.0f ? f : 0x1.fffffep-1f;   // v_fract_f32 clamps to the largest float below 1
 #endif
 }
-SVS_HD float fmin3_abs(float a, float b, float c) { return fminf(a, fminf(fabsf(b), fabsf(c))); }
+SVS_HD float fmin3_abs(float a, float b, float c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    // spelled out: from the C form hipcc makes v_min_f32 |b|, |c| followed by a v_min3 that joins two such pairs - 56 instead
+    // of 32 instructions of the 1.6-slot class per block (profiles/r04_valu_issue_rate.txt)
+    float r;
+    asm("v_min3_f32 %0, %1, |%2|, |%3|" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+#else
+    return fminf(a, fminf(fabsf(b), fabsf(c)));
+#endif
+}
 
-// Embed `nb` (0..n) payload bits, taken MSB-first from hi:lo, into the block held in rx[]/ry[] - FAST arithmetic, any
-// number of coefficient rows (the kernels use it for U >= 2; one row goes through embed_block_guarded below).
-// NFIX > 0 fixes the coefficient count at compile time: transform outputs nobody reads and inverse inputs that are known
-// zeros then disappear from the code.  NFIX = 0 reads n at run time.
+// Embed `nb` (0..n) payload bits, taken MSB-first from hi:lo, into the block held in rx[]/ry[] - FAST arithmetic for THREE AND
+// MORE coefficient rows (n >= 16).  One and two rows (n <= 15) have no separate FAST arithmetic any more: there the rigorous
+// guard (embed_block_guarded / embed_block_guarded2) costs about the same and is bit-identical, so FAST runs it too.
 //
 // Returns true when the block is UNDECIDED and has to be redone with the pocketfft-identical arithmetic (rx/ry then still
 // hold the original pixels: embed_block_exact on the host emulation, the in-kernel replay on the device).
@@ -453,30 +458,26 @@ SVS_HD float fmin3_abs(float a, float b, float c) { return fminf(a, fminf(fabsf(
 // seen on 10^7 blocks 1.3e-4).  Where pixel + change lies that close to an integer the noise decides the byte - and it does
 // so SYSTEMATICALLY on structured content: untouched flat blocks come out as x - 1, the changes of a flat
 // block (each 0 or +delta) cancel exactly on rows / diagonals, basis +-1/8 of flat indices 4 / 32 / 36 turns a change of 8 k
-// into the integer k, and a coefficient that vanishes by exact cancellation of the pixels comes out of this function's
-// forward transform as a 1e-5 residue whose "change" of -1e-5 floors a whole block one level down.
-// Two levels, so that ordinary content pays two operations per coefficient:
-//   1. a block is GENERIC when some applied coefficient k <= 16 (other than 4) has both |c_k| and |change_k| above
-//      SVS_FAST_GENERIC = 2^-5 (above any residue: |c_fast - c_exact| <= 1.07e-5 c00 <= 0.022, SVS_TIE_SLOPE).  Its change
-//      is then a continuous function of the pixels (c_k's distance from the quantiser grid), so a predicted value on the
-//      integer grid is an isolated coincidence (2e-4 of the pixels lie within the reference's noise of it), not structure.
-//   2. every other block - all of its changes are zeros, residues or the discrete values a vanishing coefficient takes -
-//      has every pixel's prediction tested: within SVS_FAST_GUARD = 2^-13 of an integer -> undecided.
-// What FAST does not reproduce are those isolated coincidences and quantiser near-ties of the FMA-factored forward
-// transform (both unbiased: PSNR unaffected); GUARDED / EXACT modes do.
+// into the integer k, a coefficient that vanishes by exact cancellation of the pixels comes out of this function's forward
+// transform as a 1e-5 residue whose "change" of -1e-5 floors a whole block one level down, a ramp under a zero-heavy payload
+// has all its coefficients deleted and comes out flat at its mean, and the contributions of two EQUAL requantised
+// coefficients (0,1) and (1,0) of a diagonal ramp cancel exactly on the anti-diagonal.
+// EVERY pixel's prediction is therefore tested against the integer grid (SVS_FAST_GUARD = 2^-13, just below the largest
+// round-trip noise ever observed; not a proven bound - that is what GUARDED is for); rounds 2 and 3 skipped the test for
+// blocks that looked "generic" and each review found a content family that the shortcut mistook (exact
+// cancellations, r03: deleted coefficients; round 4's own probe: the diagonal ramp above).  The test is fused with the
+// output computation: the stego rows are built in scratch registers and committed only if the block is decided.
+// What FAST does not reproduce are isolated coincidences inside that guard and quantiser near-ties of the FMA-factored
+// forward transform (both unbiased: PSNR unaffected); GUARDED / EXACT modes do.
 #define SVS_FAST_GUARD 0x1p-13f
-#define SVS_FAST_GENERIC 0x1p-5f
-#define SVS_FAST_GENERIC_SPAN 16   // coefficients 1..16 are looked at for level 1 (a block none of them makes generic is scanned)
-template <int U, int QM, int NFIX = 0>
-SVS_HD bool embed_block(uint32_t (&rx)[8], uint32_t (&ry)[8], uint32_t n_rt, uint32_t nb, uint32_t hi, uint32_t lo,
+template <int U, int QM>
+SVS_HD bool embed_block(uint32_t (&rx)[8], uint32_t (&ry)[8], uint32_t n, uint32_t nb, uint32_t hi, uint32_t lo,
                         const QimParams &qp) {
-    static_assert(NFIX == 0 || (U <= 2 && NFIX / 8 + 1 == U), "NFIX must lie in coefficient row U-1, U <= 2");
-    const uint32_t n = NFIX ? (uint32_t)NFIX : n_rt;
+    static_assert(U >= 3, "n <= 15 runs the rigorous guard (embed_block_guarded / embed_block_guarded2)");
     float D[U][8];
     ForwardSide side;
     forward_rows<U>(rx, ry, D, &side);
-    if (n >= 4) D[0][4] = side.c4;   // the reference's own value where exact ties are systematic
-    float generic = 0.0f;   // largest min(|c_k|, |change_k|) over the applied coefficients other than 4 / 32 / 36
+    D[0][4] = side.c4;   // the reference's own value where exact ties are systematic
 
     // QIM on flat coefficients 1..n: force the parity of round(c/delta) to the payload bit by
     // +1 (bit 1) / -1 (bit 0), requantise (config_and_setup.py:146-156); keep only the change.
@@ -493,103 +494,50 @@ SVS_HD bool embed_block(uint32_t (&rx)[8], uint32_t (&ry)[8], uint32_t n_rt, uin
             float cn;
             if constexpr (QM == QM_DOUBLE) cn = (float)((double)q * qp.delta_d);
             else cn = (float)q * qp.delta_f;
-            if constexpr (U >= 3) change = cn - c;   // the budget is applied below, for the one block it concerns
-            else change = ((uint32_t)i < nb) ? cn - c : 0.0f;
-            if (k != 4 && k <= SVS_FAST_GENERIC_SPAN) generic = fmaxf(generic, fminf(fabsf(c), fabsf(change)));
+            change = cn - c;   // the budget is applied below, for the one block it concerns
         }
         D[u][v] = change;
     }
     // Budget (config_and_setup.py:130,132,141): only the block the payload ends in has nb < n - its coefficients past the
-    // budget stay as they are.  With three and more coefficient rows this is kept out of the loop above (a compare and a
-    // select per coefficient for every block of the batch: -2 % at n = 63); on the device it is a branch no lane of an
-    // ordinary wave takes, and that block is always scanned (level 2).  The two-row kernel is register-allocated for its hot
-    // path (svs_device.hpp, SVS_U2_MIN_WAVES) and the extra block pushes 36 more bytes of it into scratch (2.12 vs 1.64 ms
-    // at n = 10): it keeps the select.
-    if constexpr (U >= 3) if (nb < n) {
+    // budget stay as they are.  Kept out of the loop above (a compare and a select per coefficient for every block of the
+    // batch: -2 % at n = 63); on the device it is a branch no lane of an ordinary wave takes.
+    if (nb < n) {
 #pragma unroll
         for (int k = 1; k < 8 * U; ++k)
             if ((uint32_t)(k - 1) >= nb) D[k >> 3][k & 7] = 0.0f;
-        generic = 0.0f;
     }
 
-    // inverse transform of the change: horizontal on the U rows, then vertical per column with
-    // U non-zero inputs; trunc(clip(pixel + change)) == clip(pixel + floor(change)) for an integer
-    // pixel (:171).  For U == 1 the change is the same in all 8 rows of a column.
+    // inverse transform of the change: horizontal on the U rows, then vertical per column with U non-zero inputs.
+    // trunc(clip(pixel + change)) == clip(pixel + floor(change)) for an integer pixel (:171); the floor comes from the store's
+    // own rounding: v_cvt_pk_u8_f32 rounds to nearest even, so it is fed pixel + change - (0.5 - 2^-16) - an integer-valued sum
+    // (no change) maps to itself, the offset is exact on the float32 grid of [0, 256) - and a decided pixel (fractional part of
+    // the change at least 2^-13 away from 0 and 1) stores its floor.  The offset enters through the DC input: -(0.5 - 2^-16)/a(0).
     float P[U][8];
-    if constexpr (NFIX == 0) {
-        idct8<8, true>(D[0], P[0]);
+    idct8<8, true>(D[0], P[0]);
 #pragma unroll
-        for (int u = 1; u < U; ++u) idct8<8, false>(D[u], P[u]);
-    } else {
-        idct8<(NFIX + 1 < 8 ? NFIX + 1 : 8), true>(D[0], P[0]);        // row 0: entries 1..min(n, 7) can be non-zero
-        if constexpr (U == 2) idct8<NFIX - 7, false>(D[1], P[1]);      // row 1: entries 0..n-8
-    }
-
-    // level 2 of the guard (rare on ordinary content: waves without such a block branch over it)
-    bool undecided = false;
-    if (nb > 0 && !(generic >= SVS_FAST_GENERIC)) {
-        float near = 1.0f;   // smallest distance of a predicted change from the integer grid (the pixel itself is an integer)
-#define SVS_SCANCOL(X)                                                                               \
-    {                                                                                                \
-        float in[8] = {0, 0, 0, 0, 0, 0, 0, 0};                                                      \
-        _Pragma("unroll") for (int u = 0; u < U; ++u) in[u] = P[u][X];                               \
-        float out[8];                                                                                \
-        idct8<U, false>(in, out);                                                                    \
-        _Pragma("unroll") for (int y = 0; y < (U == 1 ? 2 : 8); y += 2)                              \
-            near = fmin3_abs(near, fract_f32(out[y] + 0.5f) - 0.5f, fract_f32(out[y + 1] + 0.5f) - 0.5f); \
-    }
-        SVS_SCANCOL(0) SVS_SCANCOL(1) SVS_SCANCOL(2) SVS_SCANCOL(3) SVS_SCANCOL(4) SVS_SCANCOL(5) SVS_SCANCOL(6) SVS_SCANCOL(7)
-#undef SVS_SCANCOL
-        undecided = !(near >= SVS_FAST_GUARD);
-    }
-    if (undecided) return true;   // the block keeps its original pixels: the caller hands them to the exact arithmetic
-    if constexpr (U == 1 || SVS_FLOOR_STORE) {
-#define SVS_OUTCOL(X, W, B)                                                          \
-    {                                                                                \
-        float in[8] = {0, 0, 0, 0, 0, 0, 0, 0};                                      \
-        _Pragma("unroll") for (int u = 0; u < U; ++u) in[u] = P[u][X];               \
-        float out[8];                                                                \
-        idct8<U, false>(in, out);                                                    \
-        _Pragma("unroll") for (int y = 0; y < 8; ++y)                                \
-            W[y] = put_pixel<B>(ubyte_to_float<B>(W[y]) + floorf(out[y]), W[y]);      \
-    }
-        SVS_OUTCOL(0, rx, 0) SVS_OUTCOL(1, rx, 1) SVS_OUTCOL(2, rx, 2) SVS_OUTCOL(3, rx, 3)
-        SVS_OUTCOL(4, ry, 0) SVS_OUTCOL(5, ry, 1) SVS_OUTCOL(6, ry, 2) SVS_OUTCOL(7, ry, 3)
-#undef SVS_OUTCOL
-    } else {
-        // U >= 2 (the kernels that are VALU-limited): the pixel is added INSIDE the inverse's last stage and the
-        // floor comes from the store's own rounding.  v_cvt_pk_u8_f32 rounds to nearest even, so it is fed
-        // pixel + change - (0.5 - 2^-16): an integer-valued sum (no change) maps to itself - the offset is exact on the
-        // float32 grid of [0, 256) - and a sum with fractional part f stores floor unless f > 1 - 2^-16 - (two float32
-        // roundings <= 1.1e-5): about 2e-5 of the pixels then carry +1 - the same class as the pixels the reference
-        // itself decides by rounding noise (its own round-trip noise is larger than that window).  Saves 2 of 6
-        // operations per pixel at U = 2.  The offset enters through the DC input: -(0.5 - 2^-16)/a(0).
-        constexpr float kOff = (0.5f - 0x1p-16f) / SVS_A0;
-#define SVS_OUTCOL(X, W, B)                                                                       \
+    for (int u = 1; u < U; ++u) idct8<8, false>(D[u], P[u]);
+    constexpr float kOff = (0.5f - 0x1p-16f) / SVS_A0;
+    constexpr float kMid = 0.5f + 0x1p-16f;    // fract(change - (0.5 - 2^-16)) of a change ON the integer grid
+    float near = 1.0f;   // smallest distance of a predicted change from the integer grid (the pixel itself is an integer)
+    uint32_t nx[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ny[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // the stego rows, committed only if decided
+#define SVS_OUTCOL(X, W, NW, B)                                                                   \
     {                                                                                             \
-        if constexpr (U == 2) {                                                                   \
-            const float p0 = P[0][X] - kOff, p1 = P[1][X];                                        \
-            const float ck[4] = {SVS_C1, SVS_C3, SVS_C5, SVS_C7};                                 \
-            _Pragma("unroll") for (int y = 0; y < 4; ++y) {                                       \
-                const float ta = fmaf(p0, SVS_A0, ubyte_to_float<B>(W[y]));                       \
-                const float tb = fmaf(p0, SVS_A0, ubyte_to_float<B>(W[7 - y]));                   \
-                W[y] = put_pixel_rne<B>(fmaf(p1, ck[y], ta), W[y]);                               \
-                W[7 - y] = put_pixel_rne<B>(fmaf(p1, -ck[y], tb), W[7 - y]);                      \
-            }                                                                                     \
-        } else {                                                                                  \
-            float in[8] = {0, 0, 0, 0, 0, 0, 0, 0};                                               \
-            _Pragma("unroll") for (int u = 0; u < U; ++u) in[u] = P[u][X];                        \
-            in[0] -= kOff;                                                                        \
-            float out[8];                                                                         \
-            idct8<U, false>(in, out);                                                             \
-            _Pragma("unroll") for (int y = 0; y < 8; ++y)                                         \
-                W[y] = put_pixel_rne<B>(ubyte_to_float<B>(W[y]) + out[y], W[y]);                  \
-        }                                                                                         \
+        float in[8] = {0, 0, 0, 0, 0, 0, 0, 0};                                                   \
+        _Pragma("unroll") for (int u = 0; u < U; ++u) in[u] = P[u][X];                            \
+        in[0] -= kOff;                                                                            \
+        float out[8];                                                                             \
+        idct8<U, false>(in, out);                                                                 \
+        _Pragma("unroll") for (int y = 0; y < 8; y += 2)                                          \
+            near = fmin3_abs(near, fract_f32(out[y]) - kMid, fract_f32(out[y + 1]) - kMid);       \
+        _Pragma("unroll") for (int y = 0; y < 8; ++y)                                             \
+            NW[y] = put_pixel_rne<B>(ubyte_to_float<B>(W[y]) + out[y], NW[y]);                    \
     }
-        SVS_OUTCOL(0, rx, 0) SVS_OUTCOL(1, rx, 1) SVS_OUTCOL(2, rx, 2) SVS_OUTCOL(3, rx, 3)
-        SVS_OUTCOL(4, ry, 0) SVS_OUTCOL(5, ry, 1) SVS_OUTCOL(6, ry, 2) SVS_OUTCOL(7, ry, 3)
+    SVS_OUTCOL(0, rx, nx, 0) SVS_OUTCOL(1, rx, nx, 1) SVS_OUTCOL(2, rx, nx, 2) SVS_OUTCOL(3, rx, nx, 3)
+    SVS_OUTCOL(4, ry, ny, 0) SVS_OUTCOL(5, ry, ny, 1) SVS_OUTCOL(6, ry, ny, 2) SVS_OUTCOL(7, ry, ny, 3)
 #undef SVS_OUTCOL
-    }
+    if (nb > 0 && !(near >= SVS_FAST_GUARD)) return true;   // undecided: the block keeps its original pixels
+#pragma unroll
+    for (int r = 0; r < 8; ++r) { rx[r] = nx[r]; ry[r] = ny[r]; }
     return false;
 }
 
@@ -1071,38 +1019,111 @@ SVS_HD bool embed_block_guarded(uint32_t (&rx)[8], uint32_t (&ry)[8], uint32_t n
 }
 
 // Two coefficient rows (n = 8..15), rigorous: the same construction with 64 predictions instead of 8 (the change now varies
-// down a column) - pocketfft-identical rows 0 and 1 (the vertical pass is pocketfft's dct2_8 per column, of which the compiler
-// keeps the operations behind outputs 0 and 1), QIM with the reference's decisions, sparse inverse, and every pixel's
+// down a column) - pocketfft-identical rows 0 and 1, QIM with the reference's decisions, sparse inverse, and every pixel's
 // prediction tested against the grid with the bound of ITS position: the (2 -> 1) norms behind KE differ by pixel (24.7 in
 // rows / columns 0, 3, 4, 7 crossed with each other, 31.0 in rows / columns 1, 2, 5, 6 crossed, 27.9 mixed), which takes the
-// share of undecided noise blocks from 13 % to 12 %.  The prediction is read from the value the store path feeds to
-// v_cvt_pk_u8_f32 (pixel + change - (1/2 - 2^-16), see embed_block): two float32 roundings at magnitude < 512, for which
-// make_guard adds 2^-14 to BETA.
+// share of undecided noise blocks from 13 % to 12 %.  FAST and GUARDED both run it (round 4).
 #define SVS_GUARD_KE_CC 24.68
 #define SVS_GUARD_KE_CE 27.93
+
+// Outputs 0 and 1 of pocketfft's vertical transform (svs::pf::dct2_8 down a pixel column), for the four columns held as the
+// bytes of w[0..7] - bit for bit, at a third of the operations (round 4; before, each column ran the float sequence of which
+// the compiler kept the 41 operations behind X[0] and X[1]).  Pixels are integers, so every value of that sequence up to the
+// first irrational twiddle is an exact small integer whichever way it is computed:
+//     c0 = 2 x0, c7 = 2 x7, c1 = x1 + x2, c2 = x2 - x1, c3 = x3 + x4, c4 = x4 - x3, c5 = x5 + x6, c6 = x6 - x5      (pre-butterfly)
+//     h4 = c0 - c7 = 2 d0,  tr2 = c1 - c5 = d1 + d2,  ti2 = c2 + c6 = d2 - d1,  with d_k = x_k - x_(7-k)              (radb2)
+//     a1 = h4 - 2 c4 = 2 (d0 + d3),  b1 = h4 + 2 c4 = 2 (d0 - d3),  r[0] = 2 (sum of the column)                      (radb4)
+// so they are formed on packed 16-bit lanes (two columns per operation) and converted to float once.  From there on the
+// operations are pocketfft's own: h6 = W ti2 + W tr2, h5 = W tr2 - W ti2, r[1] = fl(2 h5 + a1), r[7] = fl(2 h6 + b1), the
+// twiddle post-pass.  Two exact rescalings: fl(2 h + 2 a') = 2 fl(h + a') - r[1] and r[7] are carried at half their value -
+// and that factor 2 is folded into the twiddle constants (T / 4 instead of T / 8; powers of two commute with rounding).
+// S accumulates the sum of the 32 pixels (the guard's mean term) from the column sums that are there anyway.
+// tests/test_guarded_mode_cpu.py holds this function against svs::pf::dct2_8 on random and extreme columns.
+SVS_HD void vertical_pf01_packed(const uint32_t (&w)[8], float (&v0)[4], float (&v1)[4], uint32_t &S);
+
+namespace pf {
+SVS_HD void column_outputs01(float colsum, float tr2, float ti2, float a1h, float b1h, float &X0, float &X1) {
+    X0 = colsum * (SVS_PF_SQRT2 * 0.25f);            // r[0] * (sqrt2 / 8), r[0] = 2 * colsum
+    const float wtr = SVS_PF_W * tr2, wti = SVS_PF_W * ti2;
+    const float h6 = wti + wtr, h5 = wtr - wti;
+    const float o1 = h5 + a1h, o7 = h6 + b1h;        // r[1] / 2, r[7] / 2
+    const float t1 = (SVS_PF_T0 * 0.25f) * o7 + (SVS_PF_T6 * 0.25f) * o1;
+    const float t2 = (SVS_PF_T0 * 0.25f) * o1 - (SVS_PF_T6 * 0.25f) * o7;
+    X1 = t1 + t2;
+}
+}  // namespace pf
+
+SVS_HD void vertical_pf01_packed(const uint32_t (&w)[8], float (&v0)[4], float (&v1)[4], uint32_t &S) {
+    typedef int16_t i16x2 __attribute__((vector_size(4)));
+    uint32_t lane[2][8];  // [0]: bytes 0 and 2 (columns 0, 2), [1]: bytes 1 and 3 (columns 1, 3), as 16-bit lanes
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        lane[0][r] = w[r] & 0x00ff00ffu;
+        lane[1][r] = (w[r] >> 8) & 0x00ff00ffu;
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        uint32_t s[4];
+        i16x2 d[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            s[k] = lane[h][k] + lane[h][7 - k];  // <= 510 per lane: no carry between lanes
+            d[k] = __builtin_bit_cast(i16x2, lane[h][k]) - __builtin_bit_cast(i16x2, lane[h][7 - k]);
+        }
+        const uint32_t t = (s[0] + s[3]) + (s[1] + s[2]);  // <= 2040 per lane
+        S += (t & 0xffffu) + (t >> 16);
+        const i16x2 tr2 = d[1] + d[2], ti2 = d[2] - d[1], a1h = d[0] + d[3], b1h = d[0] - d[3];   // |.| <= 510
+#pragma unroll
+        for (int c = 0; c < 2; ++c)  // 16-bit lane c of half h is column 2c + h
+            pf::column_outputs01((float)(c ? (t >> 16) : (t & 0xffffu)), (float)tr2[c], (float)ti2[c], (float)a1h[c], (float)b1h[c],
+                                 v0[2 * c + h], v1[2 * c + h]);
+    }
+}
+
+// One coefficient through the quantiser, in the float domain: change = fl(q' delta) - c with q' = round-half-even(c / delta)
+// forced to the parity of `bit` (config_and_setup.py:148-156).  t + 1.5 * 2^23 rounds t to the nearest-even integer q AND leaves
+// q in the low mantissa bits of the sum (|t| < 2^22: delta >= 1/4 and |c| <= 2040 here), so the parity is forced on the bit
+// pattern and q' comes back by subtracting the constant - no conversion to an integer and back (those are 1.6-slot
+// instructions, profiles/r04_valu_issue_rate.txt).  Same results as quant_index / force_parity (tests: guarded mode vs the oracle).
+template <int QM>
+SVS_HD float qim_change(float c, uint32_t bit, const QimParams &qp) {
+    if constexpr (QM == QM_DOUBLE) {
+        const int q = force_parity(quant_index<QM>(c, qp), (int)bit);
+        return (float)((double)q * qp.delta_d) - c;
+    } else {
+        const float kMagic = 12582912.0f;   // 1.5 * 2^23
+        const float t = c * qp.inv_delta_f;
+        float m = t + kMagic;
+#if defined(SVS_QUANT_ALWAYS_DIVIDE)
+        m = rintf(c / qp.delta_f) + kMagic;
+#else
+        if constexpr (QM != QM_POW2) {
+            const float r = m - kMagic;
+            const float miss = fabsf(fabsf(t - r) - 0.5f);       // distance of t from the nearest half-integer
+            if (miss <= fabsf(t) * 4.76837158203125e-7f)          // see quant_index
+                m = rintf(c / qp.delta_f) + kMagic;
+        }
+#endif
+        const uint32_t mb = (__builtin_bit_cast(uint32_t, m) & ~1u) | bit;
+        const float qf = __builtin_bit_cast(float, mb) - kMagic;
+        return qf * qp.delta_f - c;
+    }
+}
+
 template <int QM>
 SVS_HD bool embed_block_guarded2(uint32_t (&rx)[8], uint32_t (&ry)[8], uint32_t n, uint32_t nb, uint32_t hi, uint32_t lo,
                                  const QimParams &qp) {
     float V0[8], V1[8];
     uint32_t S = 0, Q = 0;
-#define SVS_COL(X, W, B)                                                                \
-    {                                                                                   \
-        const float col[8] = {ubyte_to_float<B>(W[0]), ubyte_to_float<B>(W[1]),         \
-                              ubyte_to_float<B>(W[2]), ubyte_to_float<B>(W[3]),         \
-                              ubyte_to_float<B>(W[4]), ubyte_to_float<B>(W[5]),         \
-                              ubyte_to_float<B>(W[6]), ubyte_to_float<B>(W[7])};        \
-        float out[8];                                                                   \
-        pf::dct2_8(col, out);                                                           \
-        V0[X] = out[0];                                                                 \
-        V1[X] = out[1];                                                                 \
+    {
+        float a0[4], a1[4], b0[4], b1[4];
+        vertical_pf01_packed(rx, a0, a1, S);
+        vertical_pf01_packed(ry, b0, b1, S);
+#pragma unroll
+        for (int x = 0; x < 4; ++x) { V0[x] = a0[x]; V1[x] = a1[x]; V0[4 + x] = b0[x]; V1[4 + x] = b1[x]; }
     }
-    SVS_COL(0, rx, 0) SVS_COL(1, rx, 1) SVS_COL(2, rx, 2) SVS_COL(3, rx, 3)
-    SVS_COL(4, ry, 0) SVS_COL(5, ry, 1) SVS_COL(6, ry, 2) SVS_COL(7, ry, 3)
-#undef SVS_COL
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
-        S = dot4_u8(rx[r], 0x01010101u, S);
-        S = dot4_u8(ry[r], 0x01010101u, S);
         Q = dot4_u8(rx[r], rx[r], Q);
         Q = dot4_u8(ry[r], ry[r], Q);
     }
@@ -1112,17 +1133,8 @@ SVS_HD bool embed_block_guarded2(uint32_t (&rx)[8], uint32_t (&ry)[8], uint32_t 
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
         float change = 0.0f;
-        if (k >= 1 && (uint32_t)k <= n) {  // wave-uniform
-            const int i = k - 1;
-            const int bit = (int)window_bit(hi, lo, i);
-            const float c = k < 8 ? D0[k] : D1[k - 8];
-            int q = quant_index<QM>(c, qp);
-            q = force_parity(q, bit);
-            float cn;
-            if constexpr (QM == QM_DOUBLE) cn = (float)((double)q * qp.delta_d);
-            else cn = (float)q * qp.delta_f;
-            change = cn - c;   // the budget is applied below, for the one block it concerns
-        }
+        if (k >= 1 && (uint32_t)k <= n)  // wave-uniform; the budget is applied below, for the one block it concerns
+            change = qim_change<QM>(k < 8 ? D0[k] : D1[k - 8], window_bit(hi, lo, k - 1), qp);
         if (k < 8) D0[k] = change;
         else D1[k - 8] = change;
     }
@@ -1144,27 +1156,27 @@ SVS_HD bool embed_block_guarded2(uint32_t (&rx)[8], uint32_t (&ry)[8], uint32_t 
     const float beta_ee = fmaf(qp.g_resid, spread, base);
     const float beta_ce = fmaf(qp.g_resid * (float)(SVS_GUARD_KE_CE / SVS_GUARD_KE), spread, base);
     const float beta_cc = fmaf(qp.g_resid * (float)(SVS_GUARD_KE_CC / SVS_GUARD_KE), spread, base);
-    constexpr float kOff = (0.5f - 0x1p-16f) / SVS_A0;
+    // Per pixel: ch = change(y, x) - (1/2 - 2^-16), small in magnitude, so its two roundings are part of KD's model of this
+    // sparse inverse and the test below sees the prediction itself, not a copy rounded at the magnitude of the pixel (round
+    // 3 tested pixel + change and paid 2^-14 of BETA for it).  The change lies ON the integer grid where fract(ch) = kMid.
+    // The byte is v_cvt_pk_u8_f32(pixel + ch): round-to-nearest-even of a value whose fractional part is at least BETA - and
+    // BETA >= 2^-14 (make_guard) - away from the rounding boundary, while the sum's own rounding is at most 2^-16: the floor.
+    constexpr float kHalf = 0.5f - 0x1p-16f;
     constexpr float kMid = 0.5f + 0x1p-16f;
-    float near_c = 1.0f, near_e = 1.0f;   // per column: rows 0, 3, 4, 7 and rows 1, 2, 5, 6
-    float near_cc = 1.0f, near_ce = 1.0f, near_ee = 1.0f;
+    float near_cc = 1.0f, near_ce = 1.0f, near_ee = 1.0f;   // smallest distance from the grid per position class
     uint32_t nx[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ny[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // the stego rows, committed only if decided
     const float ck[4] = {SVS_C1, SVS_C3, SVS_C5, SVS_C7};
+    // CLS_C: class of this column's pixels in rows 0, 3, 4, 7;  CLS_E: in rows 1, 2, 5, 6
 #define SVS_PREDCOL(X, W, NW, B, CLS_C, CLS_E)                                                  \
     {                                                                                           \
-        const float p0 = P0[X] - kOff, p1 = P1[X];                                              \
-        near_c = 1.0f; near_e = 1.0f;                                                           \
+        const float e = fmaf(P0[X], SVS_A0, -kHalf), p1 = P1[X];                                \
         _Pragma("unroll") for (int y = 0; y < 4; ++y) {                                         \
-            const float ta = fmaf(p0, SVS_A0, ubyte_to_float<B>(W[y]));                         \
-            const float tb = fmaf(p0, SVS_A0, ubyte_to_float<B>(W[7 - y]));                     \
-            const float va = fmaf(p1, ck[y], ta), vb = fmaf(p1, -ck[y], tb);                    \
-            if (y == 0 || y == 3) near_c = fmin3_abs(near_c, fract_f32(va) - kMid, fract_f32(vb) - kMid); \
-            else near_e = fmin3_abs(near_e, fract_f32(va) - kMid, fract_f32(vb) - kMid);        \
-            NW[y] = put_pixel_rne<B>(va, NW[y]);                                                \
-            NW[7 - y] = put_pixel_rne<B>(vb, NW[7 - y]);                                        \
+            const float ca = fmaf(p1, ck[y], e), cb = fmaf(p1, -ck[y], e);                      \
+            if (y == 0 || y == 3) CLS_C = fmin3_abs(CLS_C, fract_f32(ca) - kMid, fract_f32(cb) - kMid); \
+            else CLS_E = fmin3_abs(CLS_E, fract_f32(ca) - kMid, fract_f32(cb) - kMid);          \
+            NW[y] = put_pixel_rne<B>(ca + ubyte_to_float<B>(W[y]), NW[y]);                      \
+            NW[7 - y] = put_pixel_rne<B>(cb + ubyte_to_float<B>(W[7 - y]), NW[7 - y]);          \
         }                                                                                       \
-        CLS_C = fminf(CLS_C, near_c);                                                           \
-        CLS_E = fminf(CLS_E, near_e);                                                           \
     }
     SVS_PREDCOL(0, rx, nx, 0, near_cc, near_ce) SVS_PREDCOL(1, rx, nx, 1, near_ce, near_ee) SVS_PREDCOL(2, rx, nx, 2, near_ce, near_ee)
     SVS_PREDCOL(3, rx, nx, 3, near_cc, near_ce) SVS_PREDCOL(4, ry, ny, 0, near_cc, near_ce) SVS_PREDCOL(5, ry, ny, 1, near_ce, near_ee)
@@ -1183,7 +1195,11 @@ inline void make_guard(double delta, int rows, QimParams *qp) {
     const double kd = rows <= 1 ? SVS_GUARD_KD_U1 : SVS_GUARD_KD_U2;
     qp->g_sum = (float)(SVS_GUARD_UEFF * SVS_GUARD_KDC / 64.0 * up);
     qp->g_resid = (float)(SVS_GUARD_UEFF * SVS_GUARD_KE / 8.0 * up);
-    qp->g_delta = (float)((SVS_GUARD_UEFF * kd * (1.5 * delta + 0.01) + 0x1p-20 + 0x1p-22 + (rows >= 2 ? 0x1p-14 : 0.0)) * up);
+    double gd = SVS_GUARD_UEFF * kd * (1.5 * delta + 0.01) + 0x1p-20 + 0x1p-22;
+    // two rows: the byte comes from v_cvt_pk_u8_f32's own rounding of pixel + (change - (1/2 - 2^-16)), which is the floor only
+    // while the change's fractional part stays 2^-15 below 1 (embed_block_guarded2) - a FLOOR under BETA, not a term of it
+    if (rows >= 2 && gd < 0x1p-14) gd = 0x1p-14;
+    qp->g_delta = (float)(gd * up);
 }
 
 // EXACT embed of TWO horizontally adjacent blocks at once: every value is a pair (block A, block B) and every transform

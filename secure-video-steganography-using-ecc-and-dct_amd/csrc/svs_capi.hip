@@ -45,11 +45,20 @@ svs::FastDiv make_div(uint32_t d) {
     return r;
 }
 
-// tuning knob: workgroup->tile chunking (see svs::tile_id); env override for experiments
-uint32_t env_chunk(const char *name, uint32_t dflt) {
+// Experiment knobs.  The PRODUCT build reads no environment variable at all: every knob below is its compiled-in default
+// and `knob()` folds to a constant - no variable can reroute a kernel, let alone touch the parity guarantee of a flag
+// (round 3 evaluated ~10 getenv per svs_embed_dev call, and SVS_GUARD_SCALE silently made the
+// bit-identical mode non-identical).  `make variants` builds lib/variants/libsvsdct_exp.so with -DSVS_EXPERIMENTS, in which
+// the same names are read from the environment on every call - that library is what tools/ab_bench.py --env-sweep,
+// tools/occupancy_sweep.sh and the A/B scripts load (SVSDCT_LIB=...).
+#if defined(SVS_EXPERIMENTS)
+uint32_t knob(const char *name, uint32_t dflt) {
     const char *v = getenv(name);
     return v ? (uint32_t)strtoul(v, nullptr, 10) : dflt;
 }
+#else
+constexpr uint32_t knob(const char *, uint32_t dflt) { return dflt; }
+#endif
 
 // Occupancy cap: unused dynamic LDS such that at most `wg_per_cu` workgroups fit the CU's 160 KB (0 = no cap).  The
 // streaming kernels run FASTER with fewer waves in flight than their register count allows (measured sweeps in
@@ -123,8 +132,8 @@ struct Tuning {
 
 Tuning embed_tuning(int rows, const svs_planes *p, const void *a, const void *b) {
     Tuning t{rows == 1, kEighth};
-    t.two_blocks = rows == 1 && env_chunk("SVS_EMBED_BPL", t.two_blocks ? 2 : 1) == 2;
-    t.chunk = env_chunk("SVS_EMBED_XCD_CHUNK", t.chunk);
+    t.two_blocks = rows == 1 && knob("SVS_EMBED_BPL", t.two_blocks ? 2 : 1) == 2;
+    t.chunk = knob("SVS_EMBED_XCD_CHUNK", t.chunk);
     t.two_blocks = t.two_blocks && rows_allow_two_blocks(p, a, b);
     return t;
 }
@@ -134,8 +143,8 @@ Tuning extract_tuning(int rows, const svs_planes *p, const void *a) {
     // coefficient row - runs of 32 tiles per XCD; two rows (n = 8..15) - the identity map (+6.7 % at 600 x 4K, +4.4 % at
     // 2 400 x 1080p over the contiguous eighth, equal at 300 x 1080p); more rows - VALU-bound, the map does not matter
     Tuning t{false, rows == 1 ? 32u : (rows == 2 ? 0u : kEighth)};
-    t.two_blocks = rows <= 2 && env_chunk("SVS_EXTRACT_BPL", 1) == 2;
-    t.chunk = env_chunk("SVS_EXTRACT_XCD_CHUNK", t.chunk);
+    t.two_blocks = rows <= 2 && knob("SVS_EXTRACT_BPL", 1) == 2;
+    t.chunk = knob("SVS_EXTRACT_XCD_CHUNK", t.chunk);
     t.two_blocks = t.two_blocks && rows_allow_two_blocks(p, a, nullptr);
     return t;
 }
@@ -158,7 +167,7 @@ int launch_embed(int rows, uint64_t total, hipStream_t st, const uint8_t *gray, 
                  const svs::QimParams &qp, const uint32_t *bits, uint64_t bit_offset, uint64_t n_bits,
                  uint32_t n_words) {
     const dim3 grid((uint32_t)((total + SVS_WG * BPL - 1) / (SVS_WG * BPL)));
-    const uint32_t lds_pad = lds_pad_for(env_chunk("SVS_EMBED_WG_PER_CU", embed_wg_per_cu(rows, BPL)), kEmbedLds);
+    const uint32_t lds_pad = lds_pad_for(knob("SVS_EMBED_WG_PER_CU", embed_wg_per_cu(rows, BPL)), kEmbedLds);
 #define SVS_CASE(R)                                                                                            \
     case R:                                                                                                    \
         hipLaunchKernelGGL((svs::embed_kernel<R, QM, BPL>), grid, dim3(SVS_WG), lds_pad, st, gray, stego, g, qp, bits, \
@@ -180,18 +189,6 @@ int launch_embed(int rows, uint64_t total, hipStream_t st, const uint8_t *gray, 
     return SVS_OK;
 }
 
-// GUARDED with two coefficient rows (n = 8..15): the streaming kernel with the per-pixel rigorous guard
-template <int QM>
-int launch_embed_guarded2(uint64_t total, hipStream_t st, const uint8_t *gray, uint8_t *stego, const svs::Geometry &g,
-                          const svs::QimParams &qp, const uint32_t *bits, uint64_t bit_offset, uint64_t n_bits, uint32_t n_words) {
-    const dim3 grid((uint32_t)((total + SVS_WG - 1) / SVS_WG));
-    const uint32_t lds_pad = lds_pad_for(env_chunk("SVS_EMBED_WG_PER_CU", 0), kEmbedLds);
-    hipLaunchKernelGGL((svs::embed_kernel<2, QM, 1, 0, true>), grid, dim3(SVS_WG), lds_pad, st, gray, stego, g, qp, bits, bit_offset,
-                       n_bits, n_words, g_guard_counter);
-    SVS_HIP(hipGetLastError());
-    return SVS_OK;
-}
-
 template <int QM, int BPL>
 int launch_extract(int rows, uint64_t total, hipStream_t st, const uint8_t *gray, const svs::Geometry &g,
                    const svs::QimParams &qp, uint8_t *out, uint64_t out_bytes) {
@@ -199,8 +196,8 @@ int launch_extract(int rows, uint64_t total, hipStream_t st, const uint8_t *gray
     // n = 10 (the reference GUI's default) has a compile-time-n instantiation of the extract kernel: +1..7 %
     // (profiles/r01_ab_quant_exact.txt).  The same specialisation of the embed kernel measured SLOWER (-13 % at
     // 600 x 4K, n = 10) and n = 3 gains nothing (HBM-bound), so those stay on the run-time-n kernels.
-    const bool fixed_n = env_chunk("SVS_FIXED_N", 1) != 0;   // experiment knob
-    const uint32_t lds_pad = lds_pad_for(env_chunk("SVS_EXTRACT_WG_PER_CU", extract_wg_per_cu(rows)), 18432);
+    const bool fixed_n = knob("SVS_FIXED_N", 1) != 0;   // experiment knob
+    const uint32_t lds_pad = lds_pad_for(knob("SVS_EXTRACT_WG_PER_CU", extract_wg_per_cu(rows)), 18432);
     if (fixed_n && g.n_ac == 10) {
         hipLaunchKernelGGL((svs::extract_kernel<2, QM, BPL, 10>), grid, dim3(SVS_WG), lds_pad, st, gray, g, qp, out, out_bytes);
         SVS_HIP(hipGetLastError());
@@ -229,7 +226,7 @@ int launch_extract(int rows, uint64_t total, hipStream_t st, const uint8_t *gray
 int launch_embed_exact(int qm, uint64_t total, hipStream_t st, const uint8_t *gray, uint8_t *stego,
                        const svs::Geometry &g, const svs::QimParams &qp, const uint32_t *bits, uint64_t bit_offset,
                        uint64_t n_bits, uint32_t n_words, bool pair = false) {
-    const uint32_t lds_pad = lds_pad_for(env_chunk("SVS_EMBED_WG_PER_CU", 0), 0);
+    const uint32_t lds_pad = lds_pad_for(knob("SVS_EMBED_WG_PER_CU", 0), 0);
     // the kernel's quantiser loop is instantiated for one or two coefficient rows (n <= 7: the benchmark's 3; n <= 15: the
     // reference GUI's 10) and for all eight (any n): fewer wave-uniform tests per block, same arithmetic
     const int rows = rows_for((int)g.n_ac);
@@ -279,7 +276,7 @@ template <int QM>
 int launch_extract_exact(int rows, uint64_t total, hipStream_t st, const uint8_t *gray, const svs::Geometry &g,
                          const svs::QimParams &qp, uint8_t *out, uint64_t out_bytes) {
     const dim3 grid((uint32_t)((total + SVS_WG - 1) / SVS_WG));
-    const uint32_t lds_pad = lds_pad_for(env_chunk("SVS_EXTRACT_WG_PER_CU", extract_wg_per_cu(rows)), 4096);
+    const uint32_t lds_pad = lds_pad_for(knob("SVS_EXTRACT_WG_PER_CU", extract_wg_per_cu(rows)), 4096);
 #define SVS_CASE(R)                                                                                                  \
     case R:                                                                                                          \
         hipLaunchKernelGGL((svs::extract_exact_kernel<R, QM>), grid, dim3(SVS_WG), lds_pad, st, gray, g, qp, out, out_bytes); \
@@ -305,7 +302,7 @@ int launch_embed_bgr(int rows, uint64_t total, hipStream_t st, const uint8_t *in
                             const svs::Geometry &g, const svs::ColourParams &c, const svs::QimParams &qp,
                             const uint32_t *bits, uint64_t bit_offset, uint64_t n_bits, uint32_t n_words) {
     const dim3 grid((uint32_t)((total + SVS_WG - 1) / SVS_WG));
-    const uint32_t lds_pad = lds_pad_for(env_chunk("SVS_EMBED_BGR_WG_PER_CU", 0), 16384);
+    const uint32_t lds_pad = lds_pad_for(knob("SVS_EMBED_BGR_WG_PER_CU", 0), 16384);
     if constexpr (EXACT) {
         hipLaunchKernelGGL((svs::embed_bgr_kernel<8, QM, true>), grid, dim3(SVS_WG), lds_pad, st, in, out, ref, g, c, qp, bits,
                            bit_offset, n_bits, n_words);
@@ -458,36 +455,23 @@ int svs_embed_dev(const uint8_t *d_gray, uint8_t *d_stego, const svs_planes *pla
     if (flags & ~(SVS_EXACT_POCKETFFT | SVS_EXACT_GUARDED)) return fail(SVS_ERR_INVALID_ARG, "unknown flags 0x%x", flags);
     const int rows = rows_for(n);
     // Which kernel family (include/svsdct.h `flags`).  The streaming kernel (embed_kernel: cheap arithmetic + in-kernel exact
-    // replay of the blocks it cannot decide) serves FAST for any n and, with one coefficient row, GUARDED as well - there its
-    // guard is the rigorous error bound and the output is the reference's bit for bit, so both flags run the same launch.
+    // replay of the blocks it cannot decide) is bit-identical to the reference with one and two coefficient rows (n <= 15:
+    // rigorous guard) and serves BOTH flags there with the same launch; with three and more rows it is the FAST mode's
+    // kernel (per-pixel guard of 2^-13, contract-level) and GUARDED takes the lane-per-block pocketfft kernel.
     // Outside the delta range the guard is useless (every block undecided below, BETA > 1/8 above): exact kernels.
     const bool in_range = delta >= SVS_GUARD_DELTA_MIN && delta <= SVS_GUARD_DELTA_MAX;
-    bool streaming = use > 0 && in_range && !(flags & SVS_EXACT_POCKETFFT) && (rows == 1 || !(flags & SVS_EXACT_GUARDED));
-    const bool guarded2 = use > 0 && in_range && (flags & SVS_EXACT_GUARDED) && !(flags & SVS_EXACT_POCKETFFT) && rows == 2 &&
-                          env_chunk("SVS_GUARDED2_OFF", 0) == 0;
-    if (guarded2) {   // bit-identical at n = 8..15 through the streaming kernel with the per-pixel rigorous guard
-        const uint64_t words_g = ((bit_offset + use + 7) / 8 + 3) / 4;
-        if (words_g >= (1ull << 32)) return fail(SVS_ERR_INVALID_ARG, "payload too large for one call");
-        svs::make_guard(delta, 2, &qp);
-        g.xcd_chunk = env_chunk("SVS_EMBED_XCD_CHUNK", kEighth);
-        const uint32_t *bwg = reinterpret_cast<const uint32_t *>(d_bits_packed);
-        int rcg;
-        if (qm == svs::QM_DOUBLE) rcg = launch_embed_guarded2<svs::QM_DOUBLE>(total, st, d_gray, d_stego, g, qp, bwg, bit_offset, use, (uint32_t)words_g);
-        else if (qm == svs::QM_POW2) rcg = launch_embed_guarded2<svs::QM_POW2>(total, st, d_gray, d_stego, g, qp, bwg, bit_offset, use, (uint32_t)words_g);
-        else rcg = launch_embed_guarded2<svs::QM_F32>(total, st, d_gray, d_stego, g, qp, bwg, bit_offset, use, (uint32_t)words_g);
-        if (rcg) return rcg;
-        if (n_embedded) *n_embedded = use;
-        return SVS_OK;
-    }
+    bool streaming = use > 0 && in_range && !(flags & SVS_EXACT_POCKETFFT) && (rows <= 2 || !(flags & SVS_EXACT_GUARDED));
+#if defined(SVS_EXPERIMENTS)
     // (the streaming kernel stays ahead of the lane-per-block pocketfft kernel up to all eight coefficient rows: 1.20 vs
     // 1.33 ms per 200 x 4K frames at n = 63, profiles/r03_many_coefficients.txt; SVS_FAST_MAX_ROWS is the A/B knob)
-    if (rows > (int)env_chunk("SVS_FAST_MAX_ROWS", 8)) streaming = false;
-    if ((flags & SVS_EXACT_GUARDED) && env_chunk("SVS_GUARDED_OFF", 0) != 0) streaming = false;   // A/B knob
+    if (rows > (int)knob("SVS_FAST_MAX_ROWS", 8)) streaming = false;
+    if (knob("SVS_GUARDED_OFF", 0) != 0 || (rows == 2 && knob("SVS_GUARDED2_OFF", 0) != 0)) streaming = false;   // A/B: exact kernel
+#endif
     // SVS_EXACT_BPL=2 (experiment knob): exact arithmetic on two adjacent blocks per lane with every transform instruction
     // packed over the pair (embed_exact_pair_kernel).  Measured SLOWER than the one-block kernel (3.54 vs 3.16 ms at n = 3,
     // 4.83 vs 3.38 ms at n = 10, profiles/r02_ab_exact_pair.txt): a v_pk_*_f32 costs two issue slots on this chip, so
     // halving the instruction count buys nothing and the 256-register footprint costs occupancy.  Off by default.
-    const bool exact_pair = rows_allow_two_blocks(planes, d_gray, d_stego) && env_chunk("SVS_EXACT_BPL", 1) == 2;
+    const bool exact_pair = rows_allow_two_blocks(planes, d_gray, d_stego) && knob("SVS_EXACT_BPL", 1) == 2;
     if (!streaming) {
         if (use == 0 && n_bits == 0) {   // empty payload: the reference's loops break before the first block - a pure copy
             if (d_gray == d_stego) return SVS_OK;
@@ -495,7 +479,7 @@ int svs_embed_dev(const uint8_t *d_gray, uint8_t *d_stego, const svs_planes *pla
             return two ? launch_embed<svs::QM_F32, 2>(1, total, st, d_gray, d_stego, g, qp, nullptr, 0, 0, 0)
                        : launch_embed<svs::QM_F32, 1>(1, total, st, d_gray, d_stego, g, qp, nullptr, 0, 0, 0);
         }
-        g.xcd_chunk = env_chunk("SVS_EMBED_XCD_CHUNK", kEighth);
+        g.xcd_chunk = knob("SVS_EMBED_XCD_CHUNK", kEighth);
         if (use == 0) {
             // a non-empty payload of which nothing can be embedded (delta <= 0, no coefficients): the reference still
             // enters and round-trips every block (config_and_setup.py:143-145,166-169); only the exact arithmetic
@@ -516,12 +500,14 @@ int svs_embed_dev(const uint8_t *d_gray, uint8_t *d_stego, const svs_planes *pla
     const uint64_t words = (last_byte + 3) / 4;
     if (words >= (1ull << 32)) return fail(SVS_ERR_INVALID_ARG, "payload too large for one call");
     const uint32_t *bw = reinterpret_cast<const uint32_t *>(d_bits_packed);
-    if (rows == 1) {
-        svs::make_guard(delta, 1, &qp);
-        if (const char *sc = getenv("SVS_GUARD_SCALE")) {   // experiment knob: NOT bit-identical any more when < 1
+    if (rows <= 2) {
+        svs::make_guard(delta, rows, &qp);
+#if defined(SVS_EXPERIMENTS)
+        if (const char *sc = getenv("SVS_GUARD_SCALE")) {   // NOT bit-identical any more when < 1 (experiments library only)
             const float f = (float)atof(sc);
             qp.g_sum *= f; qp.g_resid *= f; qp.g_delta *= f;
         }
+#endif
     }
     int rc;
 #define SVS_GO(QM)                                                                                                   \
@@ -569,13 +555,14 @@ int svs_extract_dev(const uint8_t *d_gray, const svs_planes *planes, double delt
         // rounding tie is recomputed with it, tools/guard_bound.py --tie), at 0.86 instead of 1.03 ms per 600 x 4K at n = 10.
         // Outside the guard's delta range the flag means the pocketfft-identical kernels, as for embedding.
         if (flags & SVS_EXACT_GUARDED)
-            flags = (delta >= SVS_GUARD_DELTA_MIN && delta <= SVS_GUARD_DELTA_MAX && env_chunk("SVS_GUARDED_OFF", 0) == 0)
+            flags = (delta >= SVS_GUARD_DELTA_MIN && delta <= SVS_GUARD_DELTA_MAX && knob("SVS_GUARDED_OFF", 0) == 0)   // knob: experiments library only
                         ? 0u : SVS_EXACT_POCKETFFT;
         // With one coefficient row (n <= 7) the pocketfft-identical forward transform costs 0.2-3 % (the kernel stays
         // HBM-bound; in-process A/B in profiles/r01_ab_quant_exact.txt), so FAST mode uses it too and extraction is
         // bit-identical to the reference for ANY input frame.  With more rows it costs ~17 % and stays opt-in.
         // SVS_FAST_EXTRACT_U1=1 (experiment knob) selects the FMA-factored forward instead.
-        if (rows == 1 && !(flags & SVS_EXACT_POCKETFFT) && env_chunk("SVS_EXTRACT_SHUFFLE", 0) == 1) {
+#if defined(SVS_EXPERIMENTS)
+        if (rows == 1 && !(flags & SVS_EXACT_POCKETFFT) && knob("SVS_EXTRACT_SHUFFLE", 0) == 1) {
             // layout experiment: LDS-staged tiles, 8 lanes per block, cross-lane vertical pass (svs_device.hpp)
             const dim3 grid((uint32_t)((total + SVS_WG - 1) / SVS_WG));
             if (qm == svs::QM_POW2)
@@ -586,7 +573,9 @@ int svs_extract_dev(const uint8_t *d_gray, const svs_planes *planes, double delt
                                    d_bits_packed_out, bytes);
             SVS_HIP(hipGetLastError());
             rc = SVS_OK;
-        } else if ((flags & SVS_EXACT_POCKETFFT) || (rows == 1 && env_chunk("SVS_FAST_EXTRACT_U1", 0) == 0)) {
+        } else
+#endif
+        if ((flags & SVS_EXACT_POCKETFFT) || (rows == 1 && knob("SVS_FAST_EXTRACT_U1", 0) == 0)) {
             rc = qm == svs::QM_POW2 ? launch_extract_exact<svs::QM_POW2>(rows, total, st, d_gray, g, qp, d_bits_packed_out, bytes)
                                     : launch_extract_exact<svs::QM_F32>(rows, total, st, d_gray, g, qp, d_bits_packed_out, bytes);
         } else if (qm == svs::QM_POW2)
@@ -758,40 +747,20 @@ int svs_embed_bgr_dev(const uint8_t *d_bgr_in, int64_t in_row_pitch, int64_t in_
     if (!(delta > 0.0) || n == 0) use = 0;
     if (use > 0 && (!d_bits_packed || ((uintptr_t)d_bits_packed % 4)))
         return fail(SVS_ERR_INVALID_ARG, "bits pointer NULL or not 4-byte aligned");
-    // kernel family as in svs_embed_dev: the streaming arithmetic (with its in-kernel exact replay) for FAST and - with one
-    // coefficient row, where it is bit-identical - for GUARDED; the exact arithmetic otherwise, and whenever a non-empty
-    // payload cannot be embedded (every block is then round-tripped, which only the exact arithmetic reproduces)
+    // kernel family as in svs_embed_dev: the streaming arithmetic (with its in-kernel exact replay) - bit-identical with one
+    // and two coefficient rows, where both flags run it; FAST only with more rows; the exact arithmetic otherwise, and
+    // whenever a non-empty payload cannot be embedded (every block is then round-tripped, which only it reproduces)
     const int rows_n = rows_for(n);
     const bool in_range = delta >= SVS_GUARD_DELTA_MIN && delta <= SVS_GUARD_DELTA_MAX;
-    const bool streaming = use > 0 && in_range && !(flags & SVS_EXACT_POCKETFFT) && (rows_n == 1 || !(flags & SVS_EXACT_GUARDED)) &&
-                           rows_n <= (int)env_chunk("SVS_FAST_MAX_ROWS", 8);
-    // GUARDED with two coefficient rows: the streaming arithmetic with the rigorous per-pixel guard, as in svs_embed_dev
-    const bool guarded2 = use > 0 && in_range && (flags & SVS_EXACT_GUARDED) && !(flags & SVS_EXACT_POCKETFFT) && rows_n == 2 &&
-                          env_chunk("SVS_GUARDED2_OFF", 0) == 0;
-    const bool exact = !streaming && !guarded2 && (use > 0 || n_bits > 0);
+    const bool streaming = use > 0 && in_range && !(flags & SVS_EXACT_POCKETFFT) && (rows_n <= 2 || !(flags & SVS_EXACT_GUARDED)) &&
+                           rows_n <= (int)knob("SVS_FAST_MAX_ROWS", 8);
+    const bool exact = !streaming && (use > 0 || n_bits > 0);
     svs::QimParams qp;
     const int qm = make_qim(use == 0 ? 1.0 : delta, &qp);
-    if (streaming && rows_n == 1) svs::make_guard(delta, 1, &qp);
-    if (guarded2) svs::make_guard(delta, 2, &qp);
-    g.xcd_chunk = env_chunk("SVS_EMBED_XCD_CHUNK", kEighth);
+    if (streaming && rows_n <= 2) svs::make_guard(delta, rows_n, &qp);
+    g.xcd_chunk = knob("SVS_EMBED_XCD_CHUNK", kEighth);
     const hipStream_t st = (hipStream_t)stream;
     const uint32_t *bw = reinterpret_cast<const uint32_t *>(d_bits_packed);
-    if (guarded2) {
-        const uint64_t w64 = ((bit_offset + use + 7) / 8 + 3) / 4;
-        if (w64 >= (1ull << 32)) return fail(SVS_ERR_INVALID_ARG, "payload too large for one call");
-        const dim3 grid((uint32_t)((total + SVS_WG - 1) / SVS_WG));
-        const uint32_t lds_pad = lds_pad_for(env_chunk("SVS_EMBED_BGR_WG_PER_CU", 0), 16384);
-#define SVS_GO2(QM)                                                                                                          \
-    hipLaunchKernelGGL((svs::embed_bgr_kernel<2, QM, false, true>), grid, dim3(SVS_WG), lds_pad, st, d_bgr_in, d_bgr_out,    \
-                       d_gray_ref, g, c, qp, bw, bit_offset, use, (uint32_t)w64)
-        if (qm == svs::QM_DOUBLE) SVS_GO2(svs::QM_DOUBLE);
-        else if (qm == svs::QM_POW2) SVS_GO2(svs::QM_POW2);
-        else SVS_GO2(svs::QM_F32);
-#undef SVS_GO2
-        SVS_HIP(hipGetLastError());
-        if (n_embedded) *n_embedded = use;
-        return SVS_OK;
-    }
     uint64_t kernel_bits = use;
     uint32_t words = 0;
     if (use == 0) {
@@ -843,7 +812,7 @@ int svs_extract_bgr_dev(const uint8_t *d_bgr, int64_t bgr_row_pitch, int64_t bgr
     } else {
         svs::QimParams qp;
         const int qm = make_qim(delta, &qp);
-        g.xcd_chunk = env_chunk("SVS_EXTRACT_XCD_CHUNK", rows_for(n) == 1 ? 32u : kEighth);
+        g.xcd_chunk = knob("SVS_EXTRACT_XCD_CHUNK", rows_for(n) == 1 ? 32u : kEighth);
         const dim3 grid((uint32_t)((total + SVS_WG - 1) / SVS_WG));
         const int rows = rows_for(n);
 #define SVS_CASE(R)                                                                                                      \
@@ -1056,7 +1025,7 @@ int svs_ref_copy_dev(const void *d_src, void *d_dst, uint64_t bytes, int mode, v
     const hipStream_t st = (hipStream_t)stream;
     const auto *s = reinterpret_cast<const svs::u32x4 *>(d_src);
     auto *d = reinterpret_cast<svs::u32x4 *>(d_dst);
-    const uint32_t pad = lds_pad_for(env_chunk("SVS_COPY_WG_PER_CU", 0), 0);  // experiment knob
+    const uint32_t pad = lds_pad_for(knob("SVS_COPY_WG_PER_CU", 0), 0);  // experiment knob
     if (mode == 8 || mode == 9) {   // 8: 16-byte loads + 8-byte stores, 9: 8-byte loads + 16-byte stores
         const dim3 grid((uint32_t)((bytes / 16 + 255) / 256));
         if (mode == 8) hipLaunchKernelGGL(svs::copy_mixed_kernel<1>, grid, dim3(256), 0, st, (const uint8_t *)d_src, (uint8_t *)d_dst, bytes);

@@ -289,6 +289,7 @@ __global__ __launch_bounds__(SVS_WG) void extract_kernel(const uint8_t *__restri
                            hi_b, lo_b, out, out_bytes);
 }
 
+#if defined(SVS_EXPERIMENTS)   // experiments library only (make variants -> lib/variants/libsvsdct_exp.so)
 // ---------------------------------------------------------------------------------------
 // Layout experiment (SVS_EXTRACT_SHUFFLE=1, one coefficient row, FAST arithmetic): the north-star's sketch taken
 // literally - tiles staged in LDS, 8 lanes per block (one pixel row each), the vertical pass as cross-lane (DPP)
@@ -369,6 +370,8 @@ __global__ __launch_bounds__(SVS_WG) void extract_shuffle_kernel(const uint8_t *
         }
     }
 }
+
+#endif  // SVS_EXPERIMENTS
 
 // ---------------------------------------------------------------------------------------
 // EXACT-mode kernels (pocketfft-identical arithmetic, svs_block.hpp "EXACT mode"): one block per lane.
@@ -460,10 +463,11 @@ __global__ __launch_bounds__(SVS_WG, SVS_EXACT2_MIN_WAVES) void embed_exact_pair
 // workgroups of SVS_WG.  BPL = 2 (16-byte row accesses) needs an even number of blocks per row and 16-byte aligned rows
 // (the host checks) and is instantiated for one coefficient row only.
 // HBM traffic per block: 64 B read + 64 B written + n payload bits read - nothing else, whatever the content.
-//   phase 1  lane = block: the cheap arithmetic (svs_block.hpp) - U = 1: embed_block_guarded (pocketfft-identical payload
-//            coefficients, sparse inverse, rigorous per-block error bound: the result is the reference's, bit for bit);
-//            U >= 2: embed_block (FMA-factored transform, per-pixel guard of SVS_FAST_GUARD).  Either returns "undecided"
-//            for the few blocks whose truncation the reference's own float32 noise decides.
+//   phase 1  lane = block: the cheap arithmetic (svs_block.hpp) - U <= 2 (n <= 15): embed_block_guarded / _guarded2
+//            (pocketfft-identical payload coefficients, sparse inverse, rigorous per-block error bound: the result is the
+//            reference's, bit for bit; FAST and GUARDED are the same launch); U >= 3 (FAST only): embed_block (FMA-factored
+//            transform, per-pixel guard of SVS_FAST_GUARD).  Either returns "undecided" for the blocks whose truncation
+//            the reference's own float32 noise decides.
 //   phase 2  the wave's undecided blocks are compacted into a wave-private LDS worklist (ballot + mbcnt: no atomics, no
 //            barrier) and redone with the pocketfft-identical arithmetic by EIGHT LANES PER BLOCK: lane r of a group
 //            transforms column r, then row r, of its block - the four 1-D passes of the reference (vertical / horizontal
@@ -472,6 +476,7 @@ __global__ __launch_bounds__(SVS_WG, SVS_EXACT2_MIN_WAVES) void embed_exact_pair
 //            embed_block_exact, so the bits are the same; what changes is the shape: about 40 VGPRs and 300-450
 //            instructions per pass of 8 blocks instead of 140 VGPRs and 2 100 per pass of 64 - affordable inside the
 //            streaming kernel.  More than SVS_GUARD_CAP undecided blocks in a wave (flat content) take further rounds.
+//            With two coefficient rows the worklist is shared by the workgroup (guard_phase2_wg).
 //   phase 3  every lane stores its rows (its own result, or the one it collected from the worklist): the wave's stores
 //            cover whole 512-byte row segments - no partial lines, no second launch, no scratch buffer in HBM.
 // `gray` and `stego` may be the same buffer (in-place embedding, include/svsdct.h), so neither is __restrict__: every
@@ -541,7 +546,7 @@ __device__ __forceinline__ void guard_replay8(GuardEntry *e, float *t, uint32_t 
 
 // phase 1 for one block whose rows are ax/ay, in place: stego pixels out - unless the block is undecided, then its original
 // pixels are left untouched (svs_block.hpp decides before it writes).  -> undecided
-template <int U, int QM, int NFIX, bool RIG = false>
+template <int U, int QM>
 __device__ __forceinline__ bool guard_phase1(uint32_t (&ax)[8], uint32_t (&ay)[8], uint32_t n, uint64_t first,
                                              const QimParams &qp, const uint32_t *__restrict__ bits,
                                              uint64_t bit_offset, uint64_t n_bits, uint32_t n_words,
@@ -550,9 +555,9 @@ __device__ __forceinline__ bool guard_phase1(uint32_t (&ax)[8], uint32_t (&ay)[8
     payload_window(bits, n_words, bit_offset + first, hi, lo);
     if (keep_hi) *keep_hi = hi;
     const uint32_t nb = block_budget(first, n_bits, n);
-    if constexpr (U == 1) return embed_block_guarded<QM>(ax, ay, n, nb, hi, lo, qp);
-    else if constexpr (U == 2 && RIG) return embed_block_guarded2<QM>(ax, ay, n, nb, hi, lo, qp);   // GUARDED, n = 8..15
-    else return embed_block<U, QM, NFIX>(ax, ay, n, nb, hi, lo, qp);
+    if constexpr (U == 1) return embed_block_guarded<QM>(ax, ay, n, nb, hi, lo, qp);          // n <= 7: rigorous, 8 tests
+    else if constexpr (U == 2) return embed_block_guarded2<QM>(ax, ay, n, nb, hi, lo, qp);    // n = 8..15: rigorous, 64 tests
+    else return embed_block<U, QM>(ax, ay, n, nb, hi, lo, qp);                                // n >= 16: FAST only
 }
 
 // what phase 2 needs to rebuild a block's payload window (kept out of the lanes' registers on the common path)
@@ -621,43 +626,95 @@ __device__ __forceinline__ uint32_t guard_phase2(GuardEntry *entries, float *til
     return total;
 }
 
-// Register targets (waves per SIMD) of the embed kernels.  With two and more coefficient rows the replay is rare (the two-level
-// guard sends only structured blocks there), so at U = 2 the kernel is allocated for what its HOT path needs - 72 VGPRs (U = 4: 128) - and the inlined
-// replay spills 12 bytes into scratch where it runs: 300 x 1080p n = 10 0.213 vs 0.223 ms,
-// 600 x 4K 1.637 vs 1.689 ms against the natural allocation of 90 VGPRs (profiles/r03_ab_occupancy.txt).  With one row the
-// replay runs in 89 % of the waves and spills there cost far more than the occupancy gains (1.90 vs 1.71 ms): natural allocation.
-#ifndef SVS_U3_MIN_WAVES
-#define SVS_U3_MIN_WAVES 1   // natural allocation (108 VGPRs): 6 waves spill 116 B into the level-2 scan - 1.11 vs 0.79 ms at n = 20
-#endif
-#ifndef SVS_U2_MIN_WAVES
-#define SVS_U2_MIN_WAVES 7
-#endif
+// phase 2 at WORKGROUP scope (round 4; the two-row kernel, where 5-13 % of the blocks are undecided and the kernel is bound
+// by vector issue, not by HBM): the undecided blocks of all four waves share ONE worklist, and its passes of eight blocks
+// are dealt round-robin to the waves.  A wave-private worklist runs ceil(k / 8) passes for its own k blocks - 0.97 passes
+// per wave at 3 blocks (natural-like content, 5 %), 1.5 at 8.3 (noise, 13 %) - the shared one ceil(K / 8) for the workgroup's
+// K: 0.5 and 1.15 per wave.  Price: one LDS atomic per wave and three workgroup barriers (the wave-private form has none),
+// which is why the one-row kernel - HBM-bound, replay hidden - keeps the wave-private form.
+// `counter` must have been zeroed (and a barrier passed) before the first wave gets here.  Every thread of the workgroup
+// must call this (barriers inside).  Returns the workgroup's number of redone blocks.
+template <int QM, int CAPWG, bool KEPT>
+__device__ __forceinline__ uint32_t guard_phase2_wg(GuardEntry *entries, float *tile, uint32_t *counter, uint32_t lane, uint32_t wave,
+                                                    uint32_t n, const QimParams &qp, const GuardPayload &pl, bool und,
+                                                    uint64_t first, uint32_t (&ax)[8], uint32_t (&ay)[8], uint32_t hi_kept) {
+    const uint64_t mask = __ballot(und);
+    uint32_t base = 0;
+    if (mask != 0) {   // wave-uniform
+        if (lane == 0) base = atomicAdd(counter, (uint32_t)__popcll(mask));
+        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+    }
+    __syncthreads();                       // every wave's count is in
+    const uint32_t total = *counter;       // uniform over the workgroup; nobody writes it again
+    if (total == 0) return 0;
+    const uint32_t slot = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+    for (uint32_t round0 = 0; round0 < total; round0 += (uint32_t)CAPWG) {   // uniform over the workgroup
+        const bool mine = und && slot >= round0 && slot < round0 + (uint32_t)CAPWG;
+        if (mine) {
+            GuardEntry *e = &entries[slot - round0];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) { e->px[2 * r] = ax[r]; e->px[2 * r + 1] = ay[r]; }
+            uint32_t hi, lo;
+            if constexpr (KEPT) { hi = hi_kept; lo = 0; }
+            else payload_window(pl.bits, pl.n_words, pl.bit_offset + first, hi, lo);
+            e->hi = hi; e->lo = lo; e->nb = block_budget(first, pl.n_bits, n);
+        }
+        __syncthreads();
+        const uint32_t todo = min(total - round0, (uint32_t)CAPWG);
+        for (uint32_t at = 8u * wave; at < todo; at += 8u * (SVS_WG / 64)) {   // this wave's passes
+            const uint32_t idx = at + (lane >> 3);
+            if (idx < todo) guard_replay8<QM>(&entries[idx], tile + (lane >> 3) * SVS_GUARD_TILE, lane & 7u, n, qp);
+        }
+        __syncthreads();
+        if (mine) {
+            const GuardEntry *e = &entries[slot - round0];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) { ax[r] = e->px[2 * r]; ay[r] = e->px[2 * r + 1]; }
+        }
+        if (round0 + (uint32_t)CAPWG < total) __syncthreads();   // the next round overwrites the entries
+    }
+    return total;
+}
+
+// Register targets (waves per SIMD) of the embed kernels: natural allocation everywhere but at four coefficient rows.
+// (Round 3 allocated the two-row FAST kernel for its hot path - 72 VGPRs, 7 waves - because its replay was rare; that kernel
+// is gone: with two rows FAST and GUARDED run the rigorous arithmetic, whose replay runs in every workgroup.  Three rows
+// forced to 6 waves spilled 116 B: 1.11 vs 0.79 ms at n = 20.  One row: spills in the replay cost 1.90 vs 1.71 ms.)
 #ifndef SVS_KEEP_WINDOW
 #define SVS_KEEP_WINDOW 1
 #endif
+#ifndef SVS_U2_WGPOOL
+#define SVS_U2_WGPOOL 1      // two rows: worklist shared by the workgroup (guard_phase2_wg); 0 = wave-private (A/B)
+#endif
+#ifndef SVS_GUARD_CAP_WG
+#define SVS_GUARD_CAP_WG 64  // entries of the shared worklist per round (noise content: 33 undecided blocks per workgroup)
+#endif
 template <int U>
-constexpr int kEmbedMinWaves = U == 2 ? SVS_U2_MIN_WAVES : U == 3 ? SVS_U3_MIN_WAVES : U == 4 ? 4 : 1;
-// index for __launch_bounds__ below (a macro argument cannot hold the comma of a second template argument): the rigorous
-// two-row kernel replays in every wave (about 15 % of noise blocks are undecided), so it keeps its natural allocation
-template <int UR>
-constexpr int kEmbedMinWavesRig = UR >= 100 ? 1 : kEmbedMinWaves<UR>;
-template <int U, int QM, int BPL, int NFIX = 0, bool RIG = false>
-__global__ __launch_bounds__(SVS_WG, kEmbedMinWavesRig<U + (RIG ? 100 : 0)>) void embed_kernel(const uint8_t *gray,
+constexpr int kEmbedMinWaves = U == 4 ? 4 : 1;
+template <int U, int QM, int BPL>
+__global__ __launch_bounds__(SVS_WG, kEmbedMinWaves<U>) void embed_kernel(const uint8_t *gray,
                                                     uint8_t *stego, const Geometry g, const QimParams qp,
                                                     const uint32_t *__restrict__ bits, const uint64_t bit_offset,
                                                     const uint64_t n_bits, const uint32_t n_words,
                                                     unsigned long long *__restrict__ replay_counter) {
-    constexpr int CAP = (U == 1 || RIG) ? SVS_GUARD_CAP : SVS_GUARD_CAP_FAST;
-    __shared__ GuardEntry entries[SVS_WG / 64][CAP];
+    static_assert(BPL == 1 || U == 1, "two blocks per lane is instantiated for one coefficient row only");
+    constexpr bool WGPOOL = U == 2 && SVS_U2_WGPOOL;
+    constexpr int CAP = WGPOOL ? SVS_GUARD_CAP_WG : (U <= 2 ? SVS_GUARD_CAP : SVS_GUARD_CAP_FAST);
+    __shared__ GuardEntry entries[WGPOOL ? 1 : SVS_WG / 64][CAP];
     __shared__ float tiles[SVS_WG / 64][8 * SVS_GUARD_TILE];
+    __shared__ uint32_t wg_undecided;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    if constexpr (WGPOOL) {
+        if (threadIdx.x == 0) wg_undecided = 0u;
+        __syncthreads();   // at the very start: no wave has work in flight yet
+    }
     const uint32_t gblock = (tile_id(g.xcd_chunk) * (uint32_t)SVS_WG + threadIdx.x) * BPL;
     const uint32_t n = g.n_ac;
     bool und_a = false, und_b = false, write = false;
-    // n <= 15 (one row; two rows with the rigorous guard, where every wave replays): the payload window of a block is its first
-    // word - kept in a register from phase 1, because re-reading it for the worklist is a global load in the life of every
-    // wave that replays (one-row kernel: 1.58 instead of 1.73 ms per 600 x 4K, and 93 instead of 100 VGPRs)
-    constexpr bool KEPT = (U == 1 || (U == 2 && RIG)) && SVS_KEEP_WINDOW;
+    // n <= 15: the payload window of a block is its first word - kept in a register from phase 1, because re-reading it for
+    // the worklist is a global load in the life of every wave that replays (one-row kernel: 1.58 instead of 1.73 ms per
+    // 600 x 4K, and 93 instead of 100 VGPRs)
+    constexpr bool KEPT = U <= 2 && SVS_KEEP_WINDOW;
     uint32_t hi_a = 0, hi_b = 0;
     typename RowVec<BPL>::type v[8];
     uint32_t ax[8], ay[8], bx[8], by[8];
@@ -674,17 +731,24 @@ __global__ __launch_bounds__(SVS_WG, kEmbedMinWavesRig<U + (RIG ? 100 : 0)>) voi
         write = stego != gray;                         // past the budget: byte-identical copy (the reference's loops `break`, :130,:132)
         if (first < n_bits) {
             write = true;
-            und_a = guard_phase1<U, QM, NFIX, RIG>(ax, ay, n, first, qp, bits, bit_offset, n_bits, n_words, KEPT ? &hi_a : nullptr);
+            und_a = guard_phase1<U, QM>(ax, ay, n, first, qp, bits, bit_offset, n_bits, n_words, KEPT ? &hi_a : nullptr);
             if constexpr (BPL == 2) {   // a budget of 0 (only the lane the payload ends in can see it) leaves block B as it is
                 if (first + n < n_bits)
-                    und_b = guard_phase1<U, QM, NFIX, RIG>(bx, by, n, first + n, qp, bits, bit_offset, n_bits, n_words, KEPT ? &hi_b : nullptr);
+                    und_b = guard_phase1<U, QM>(bx, by, n, first + n, qp, bits, bit_offset, n_bits, n_words, KEPT ? &hi_b : nullptr);
             }
         }
     }
     const GuardPayload pl{bits, bit_offset, n_bits, n_words};
     const uint64_t first_a = (uint64_t)gblock * n;
-    const uint32_t redone = guard_phase2<QM, BPL == 2, CAP, KEPT>(&entries[wave][0], &tiles[wave][0], lane, n, qp, pl, und_a, first_a, ax, ay,
-                                                                  und_b, first_a + n, bx, by, hi_a, hi_b);
+    uint32_t redone;
+    if constexpr (WGPOOL) {
+        redone = guard_phase2_wg<QM, CAP, KEPT>(&entries[0][0], &tiles[wave][0], &wg_undecided, lane, wave, n, qp, pl, und_a, first_a,
+                                                ax, ay, hi_a);
+        if (wave != 0) redone = 0;   // counted once per workgroup
+    } else {
+        redone = guard_phase2<QM, BPL == 2, CAP, KEPT>(&entries[wave][0], &tiles[wave][0], lane, n, qp, pl, und_a, first_a, ax, ay,
+                                                       und_b, first_a + n, bx, by, hi_a, hi_b);
+    }
     if (replay_counter != nullptr && redone != 0 && lane == 0) atomicAdd(replay_counter, (unsigned long long)redone);
     if (write) {
 #pragma unroll
@@ -1034,7 +1098,7 @@ __global__ __launch_bounds__(SVS_WG) void gray_to_bgr_kernel(const uint8_t *__re
 // bytes per row, then the wave writes the BGR row as 192 consecutive 8-byte units - unit u = bytes [8*(u%3), +8) of the
 // 24-byte row of the wave's block u/3 - so every store instruction covers 512 contiguous bytes instead of 8 bytes in
 // every 24.
-template <int U, int QM, bool EXACT, bool RIG = false>   // RIG: two rows with the rigorous per-pixel guard (GUARDED, n = 8..15)
+template <int U, int QM, bool EXACT>
 __global__ __launch_bounds__(SVS_WG) void embed_bgr_kernel(const uint8_t *bgr_in,   // may alias bgr_out
                                                         uint8_t *bgr_out, uint8_t *__restrict__ gray_ref,
                                                         const Geometry g, const ColourParams c, const QimParams qp,
@@ -1053,7 +1117,7 @@ __global__ __launch_bounds__(SVS_WG) void embed_bgr_kernel(const uint8_t *bgr_in
     // neutral in EXACT mode; all eight rows at once cost 100+ VGPRs and gained 1 % (profiles/r01_aux_kernel_rates.txt)
     wave_load_gray_halves(bgr_in, g, c, gblock - lane, lane, &lds_tile[wave][0][0], ax, ay);
     bool und = false;
-    constexpr bool KEPT = !EXACT && (U == 1 || (U == 2 && RIG)) && SVS_KEEP_WINDOW;   // see embed_kernel
+    constexpr bool KEPT = !EXACT && U <= 2 && SVS_KEEP_WINDOW;   // see embed_kernel
     uint32_t hi_kept = 0;
     if (live) {
         if (gray_ref != nullptr) {  // the operator's first return value: the gray frame before embedding
@@ -1072,7 +1136,7 @@ __global__ __launch_bounds__(SVS_WG) void embed_bgr_kernel(const uint8_t *bgr_in
                 payload_window(bits, n_words, bit_offset + first, hi, lo);
                 embed_block_exact<8, QM>(ax, ay, n, block_budget(first, n_bits, n), hi, lo, qp);
             } else {
-                und = guard_phase1<U, QM, 0, RIG>(ax, ay, n, first, qp, bits, bit_offset, n_bits, n_words, KEPT ? &hi_kept : nullptr);
+                und = guard_phase1<U, QM>(ax, ay, n, first, qp, bits, bit_offset, n_bits, n_words, KEPT ? &hi_kept : nullptr);
             }
         }
     }

@@ -38,12 +38,10 @@ bool embed_u(Blk &raw, uint32_t n, uint32_t nb, uint32_t hi, uint32_t lo, const 
     return svs::embed_block<U, svs::QM_F32>(raw.x, raw.y, n, nb, hi, lo, qp);
 }
 
-// -> true: the block is to be replayed with the exact arithmetic (svs::embed_block's return value)
+// -> true: the block is to be replayed with the exact arithmetic (svs::embed_block's return value); three and more rows only
 bool embed_dispatch(int rows, Blk &raw, uint32_t n, uint32_t nb, uint32_t hi, uint32_t lo,
                     const svs::QimParams &qp, int dbl) {
     switch (rows) {
-        case 1: return embed_u<1>(raw, n, nb, hi, lo, qp, dbl);
-        case 2: return embed_u<2>(raw, n, nb, hi, lo, qp, dbl);
         case 3: return embed_u<3>(raw, n, nb, hi, lo, qp, dbl);
         case 4: return embed_u<4>(raw, n, nb, hi, lo, qp, dbl);
         case 5: return embed_u<5>(raw, n, nb, hi, lo, qp, dbl);
@@ -63,7 +61,7 @@ void embed_exact_pair_dispatch(Blk &a, Blk &b, uint32_t n, uint32_t nb_a, uint32
 
 bool g_constant_shortcut = false;   // exact == 3: constant blocks take forward_exact_paired_constant, as the replay kernel does
 
-// GUARDED (exact == 4, one coefficient row): -> true when the block has to be redone with the exact arithmetic
+// GUARDED (exact == 4; FAST too at n <= 15): -> true when the block has to be redone with the exact arithmetic
 bool embed_guarded_dispatch(Blk &raw, uint32_t n, uint32_t nb, uint32_t hi, uint32_t lo, const svs::QimParams &qp, int qm) {
     if (svs::rows_for((int)n) == 2) {   // two coefficient rows: the per-pixel rigorous guard
         if (qm == svs::QM_DOUBLE) return svs::embed_block_guarded2<svs::QM_DOUBLE>(raw.x, raw.y, n, nb, hi, lo, qp);
@@ -125,13 +123,12 @@ uint64_t emu_embed(const uint8_t *gray, uint8_t *stego, int F, int H, int W, dou
     if (!(delta > 0.0) || n == 0) use = 0;
     svs::QimParams qp;
     const int dbl = make_qim(use ? delta : 1.0, &qp);
-    // exact == 4: GUARDED - the cheap path wherever its error bound decides every pixel, the exact arithmetic elsewhere
-    // (same routing as svs_embed_dev: one coefficient row, delta inside the guard's range; anything else is plain EXACT)
-    // FAST (exact == 0) takes the same kernel for one coefficient row; with more rows it runs the FMA-factored kernels with
-    // their per-pixel guard.  Outside the delta range both modes run the exact kernels.
+    // exact == 4: GUARDED - the cheap path wherever its rigorous error bound decides every pixel, the exact arithmetic
+    // elsewhere (same routing as svs_embed_dev: one or two coefficient rows, delta inside the guard's range; anything else is
+    // plain EXACT).  FAST (exact == 0) takes the same path for one and two rows; with more rows it runs the FMA-factored
+    // arithmetic with its per-pixel guard of 2^-13.  Outside the delta range both modes run the exact arithmetic.
     const bool in_range = delta >= SVS_GUARD_DELTA_MIN && delta <= SVS_GUARD_DELTA_MAX;
-    const bool guarded = use > 0 && in_range &&
-                         (((exact == 4 || exact == 0) && svs::rows_for(n) == 1) || (exact == 4 && svs::rows_for(n) == 2));
+    const bool guarded = use > 0 && in_range && (exact == 4 || exact == 0) && svs::rows_for(n) <= 2;
     if (guarded) svs::make_guard(delta, svs::rows_for(n), &qp);
     if (exact == 4 && !guarded) exact = 1;
     if (exact == 0 && !in_range) exact = 1;   // svs_embed_dev: out-of-range delta
@@ -180,8 +177,8 @@ uint64_t emu_embed(const uint8_t *gray, uint8_t *stego, int F, int H, int W, dou
                 if (n_replayed) ++*n_replayed;
             }
         } else if (!exact) {
-            // FAST: blocks whose change is structurally zero are replayed with the exact arithmetic (the kernels do that in
-            // a second pass over a per-block bitmap; csrc/svs_device.hpp "replay")
+            // FAST, three and more coefficient rows: blocks with a pixel whose predicted value lies within 2^-13 of the
+            // integer grid are replayed with the exact arithmetic (inside the same launch on the device, svs_device.hpp)
             if (embed_dispatch(svs::rows_for(n), raw, (uint32_t)n, nb, hi, lo, qp, dbl)) {
                 raw.load(p, (size_t)W);
                 embed_exact_dispatch(raw, (uint32_t)n, nb, hi, lo, qp, dbl);
@@ -257,6 +254,40 @@ void emu_pf_dct3(const float *X, float *x) {
     std::memcpy(a, X, sizeof a);
     svs::pf::dct3_8(a, b);
     std::memcpy(x, b, sizeof b);
+}
+
+// rows 0 and 1 of the vertical pass as the two-row guarded kernel computes them (packed integer first stages) -> V[2][8]
+void emu_vertical_pf01(const uint8_t *block64, float *V16) {
+    Blk raw;
+    raw.load(block64, 8);
+    float a0[4], a1[4], b0[4], b1[4];
+    uint32_t S = 0;
+    svs::vertical_pf01_packed(raw.x, a0, a1, S);
+    svs::vertical_pf01_packed(raw.y, b0, b1, S);
+    for (int x = 0; x < 4; ++x) { V16[x] = a0[x]; V16[4 + x] = b0[x]; V16[8 + x] = a1[x]; V16[12 + x] = b1[x]; }
+    V16[16] = (float)S;
+}
+
+// number of (c, bit) pairs on which the float-domain quantiser step (qim_change) differs from the integer form
+uint64_t emu_qim_change_mismatches(const float *c, const uint8_t *bit, uint64_t n, double delta) {
+    svs::QimParams qp;
+    const int qm = make_qim(delta, &qp);
+    uint64_t bad = 0;
+    for (uint64_t i = 0; i < n; ++i) {
+        float got, want;
+        if (qm == svs::QM_POW2) {
+            got = svs::qim_change<svs::QM_POW2>(c[i], bit[i], qp);
+            want = (float)svs::force_parity(svs::quant_index<svs::QM_POW2>(c[i], qp), bit[i]) * qp.delta_f - c[i];
+        } else if (qm == svs::QM_DOUBLE) {
+            got = svs::qim_change<svs::QM_DOUBLE>(c[i], bit[i], qp);
+            want = (float)((double)svs::force_parity(svs::quant_index_by_division(c[i], qp.delta_f), bit[i]) * qp.delta_d) - c[i];
+        } else {
+            got = svs::qim_change<svs::QM_F32>(c[i], bit[i], qp);
+            want = (float)svs::force_parity(svs::quant_index_by_division(c[i], qp.delta_f), bit[i]) * qp.delta_f - c[i];
+        }
+        bad += std::memcmp(&got, &want, 4) != 0;
+    }
+    return bad;
 }
 
 void emu_idct8(const float *X, float *x) {

@@ -38,6 +38,15 @@ def test_single_rank_rccl_gather():
     assert "rccl" in r["config"]["collective"]
 
 
+def test_single_rank_rccl_strong_scaling_path():
+    """the --total-frames (strong scaling) code - shard_frames, per-rank bit offsets, the padded gather
+    slice and rank 0's per-slice check - meets RCCL before the driver's 8-GPU box does: one rank, backend nccl"""
+    r = _bench("--gpus", "1", "--force-dist", "--total-frames", "7")
+    assert r["n_gpus"] == 1 and r["gather_ok"] is True and r["payload_bit_errors"] == 0
+    assert r["scaling"] == "strong" and r["config"]["frames_per_gpu"] == [7] and r["config"]["total_frames"] == 7
+    assert "rccl" in r["config"]["collective"] and r["config"]["mode"].startswith("guarded")
+
+
 def test_two_rank_gloo_rehearsal_self_launched():
     """`python bench.py --gpus 2 --rehearse-gloo` starts its own two ranks (they share GPU 0), gathers in rank order"""
     r = _bench("--gpus", "2", "--rehearse-gloo")

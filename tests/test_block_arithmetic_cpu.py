@@ -6,8 +6,8 @@ import numpy as np
 import pytest
 from scipy.fftpack import dct, idct
 
-from testlib import (CONTRACT_POINTS, case_inputs, emu_embed, emu_extract, golden_bits, hostemu, single_frame_cases,
-                     structured_covers)
+from testlib import (CONTRACT_POINTS, SMOOTH_COVERS, case_inputs, contract_payloads, emu_embed, emu_extract, golden_bits,
+                     hostemu, psnr_gap, single_frame_cases, structured_covers)
 from svsdct import batch
 from oracle import qim_dct_oracle as orc
 from svsdct import synth
@@ -89,19 +89,41 @@ def test_fast_mode_psnr_contract_on_structured_content(n_ac, delta):
     h, w = 256, 384
     for name, cover in structured_covers(h, w).items():
         cap = batch.capacity_bits(1, h, w, n_ac)
-        payload = synth.synthetic_bits(cap, seed=n_ac * 100 + delta)
-        replayed = []
-        stego, used = emu_embed(cover, delta, n_ac, payload, replayed=replayed)
-        _, ref, ref_used = orc.frame_embed(cover, delta, payload, n_ac)
-        assert used == ref_used == cap
-        a, b = orc.psnr_u8(cover, stego[0]), orc.psnr_u8(cover, ref)
-        assert abs(a - b) <= PSNR_TOL_DB, (name, a, b)
-        if name in ("flat_128", "half_letterbox", "checker_8") or (name == "constant_rows" and n_ac <= 7):
-            assert replayed[0] > 0, name                 # the slow path is really exercised
-        if delta >= 8 and cover.min() >= 16 and cover.max() < 240:      # no clipping, delta >= 8: error-free
-            assert np.array_equal(orc.frame_extract_bits(stego[0], delta, n_ac), payload), name
-        for src in (stego[0], ref, cover):
-            assert np.array_equal(emu_extract(src, delta, n_ac), orc.frame_extract_bits(src, delta, n_ac)), name
+        for pname, payload in contract_payloads(cap, seed=n_ac * 100 + delta).items():
+            replayed = []
+            stego, used = emu_embed(cover, delta, n_ac, payload, replayed=replayed)
+            _, ref, ref_used = orc.frame_embed(cover, delta, payload, n_ac)
+            assert used == ref_used == cap
+            a, b = orc.psnr_u8(cover, stego[0]), orc.psnr_u8(cover, ref)
+            assert psnr_gap(a, b) <= PSNR_TOL_DB, (name, pname, a, b)
+            if pname == "bernoulli_half" and (name in ("flat_128", "half_letterbox", "checker_8") or
+                                              (name == "constant_rows" and n_ac <= 7)):
+                assert replayed[0] > 0, name                 # the slow path is really exercised
+            # delta >= 8 is error-free unless a pixel clips (large steps do clip: 1.5 * 64 per coefficient):
+            # wherever the reference's own round trip returns the payload, so does this one
+            if delta >= 8 and np.array_equal(orc.frame_extract_bits(ref, delta, n_ac), payload):
+                assert np.array_equal(orc.frame_extract_bits(stego[0], delta, n_ac), payload), (name, pname)
+            for src in (stego[0], ref, cover) if pname == "bernoulli_half" else (stego[0],):
+                assert np.array_equal(emu_extract(src, delta, n_ac), orc.frame_extract_bits(src, delta, n_ac)), (name, pname)
+
+
+@pytest.mark.parametrize("n_ac,delta", [(8, 20), (10, 20), (10, 32), (10, 64), (11, 64), (15, 100), (16, 64), (63, 64)])
+def test_fast_mode_on_smooth_content_with_zero_heavy_payloads(n_ac, delta):
+    """VERDICT r03 weak #1, at the size of the review's probe (544 x 960): smooth ramps / sinusoid / sigma-1 Gaussian /
+    near-black under all-zero and 1 %-ones payloads.  Before the q' != 0 condition of embed_block's level 1 the horizontal
+    ramp was +0.59 dB off the oracle with no block replayed."""
+    h, w = 544, 960
+    covers = structured_covers(h, w)
+    for name in SMOOTH_COVERS:
+        cover = covers[name]
+        cap = batch.capacity_bits(1, h, w, n_ac)
+        for pname, payload in contract_payloads(cap, seed=n_ac * 100 + delta).items():
+            stego, used = emu_embed(cover, delta, n_ac, payload)
+            _, ref, ref_used = orc.frame_embed(cover, delta, payload, n_ac)
+            assert used == ref_used == cap
+            a, b = orc.psnr_u8(cover, stego[0]), orc.psnr_u8(cover, ref)
+            assert psnr_gap(a, b) <= PSNR_TOL_DB, (name, pname, a, b)
+            assert np.array_equal(emu_extract(stego[0], delta, n_ac), orc.frame_extract_bits(stego[0], delta, n_ac)), (name, pname)
 
 
 def test_fast_extraction_takes_the_exact_path_only_near_ties():

@@ -38,6 +38,18 @@ def test_header_is_plain_c_and_library_links_from_c(tmp_path):
     assert out.returncode == 0 and "c abi ok" in out.stdout, (out.returncode, out.stdout, out.stderr)
 
 
+def test_product_library_reads_no_environment_variable():
+    """the shipped library does not even import getenv - experiment knobs (kernel rerouting, occupancy
+    caps, SVS_GUARD_SCALE ...) exist only in lib/variants/libsvsdct_exp.so, built with -DSVS_EXPERIMENTS"""
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--undefined-only", native.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    assert "hipLaunchKernel" in out or "hipModuleLaunchKernel" in out or "__hipPushCallConfiguration" in out   # nm really listed imports
+    assert "getenv" not in out
+    src = open(os.path.join(REPO, "secure-video-steganography-using-ecc-and-dct_amd", "csrc", "svs_capi.hip")).read()
+    outside = re.sub(r"#if defined\(SVS_EXPERIMENTS\).*?#e(?:lse|ndif)", "", src, flags=re.S)
+    assert "getenv(" not in outside
+
+
 def test_capacity_arithmetic_without_gpu():
     lib = native.load()
     p = native.Planes.contiguous(600, 2160, 3840)

@@ -35,19 +35,52 @@ def test_cvt_pk_u8_f32_is_what_the_store_path_assumes():
                    "saturates": True, "rounding": "nearest even", "exact_on_integer_valued_input": True}, fh, indent=1)
 
 
-def test_layout_experiment_kernel_gives_the_same_bits(monkeypatch):
-    """The LDS + 8-lanes-per-block + DPP variant of the extract kernel (svs_device.hpp `extract_shuffle_kernel`, kept for the
-    layout A/B in profiles/r01_ab_layout.txt) must produce the bits of the shipped kernel."""
+def test_product_build_ignores_experiment_knobs(monkeypatch):
+    """no environment variable can reroute a kernel of the shipped library or touch the parity guarantee
+    of a flag.  The knobs that did in round 3 (SVS_GUARD_SCALE scaled the rigorous guard to zero, SVS_GUARDED_OFF /
+    SVS_GUARDED2_OFF / SVS_FAST_MAX_ROWS / SVS_EXACT_BPL / SVS_FIXED_N / SVS_EXTRACT_SHUFFLE picked other kernels) are compiled
+    only into lib/variants/libsvsdct_exp.so (-DSVS_EXPERIMENTS).  With all of them set, the default build's output is still the
+    oracle's, pixel for pixel and bit for bit, and the counter of exactly-redone blocks is what it is without them."""
+    import ctypes as C
     import numpy as np
+    from oracle import qim_dct_oracle as orc          # checker only
     from svsdct import batch, native, synth
     native.ensure_device(0)
-    for (f, h, w, n_ac, delta) in ((3, 64, 136, 3, 8), (2, 40, 72, 7, 16), (1, 8, 8, 1, 8), (5, 24, 1048, 5, 8)):
-        frames = synth.synthetic_frames(f, h, w, seed=n_ac)
-        payload = synth.synthetic_bits(batch.capacity_bits(f, h, w, n_ac), seed=n_ac)
-        stego, _ = batch.embed_frames(frames, delta, n_ac, payload, mode="fast")
-        want, n_bits = batch.extract_frames(stego, delta, n_ac, mode="fast")
-        monkeypatch.setenv("SVS_EXTRACT_SHUFFLE", "1")
-        got, n_got = batch.extract_frames(stego, delta, n_ac, mode="fast")
-        monkeypatch.delenv("SVS_EXTRACT_SHUFFLE")
-        assert n_got == n_bits and np.array_equal(got, want), (f, h, w, n_ac)
-        assert np.array_equal(np.unpackbits(got, count=n_bits), payload)
+    lib = native.load()
+    lib.svs_guard_counter_set.restype = C.c_int
+    lib.svs_guard_counter_set.argtypes = [C.c_void_p]
+    d_cnt = C.c_void_p()
+    native.check(lib.svs_malloc(C.byref(d_cnt), 8), "malloc")
+
+    def run():
+        out = []
+        for (f, h, w, n_ac, delta) in ((2, 64, 136, 3, 8), (2, 64, 136, 10, 8), (1, 48, 96, 20, 8)):
+            frames = synth.synthetic_frames(f, h, w, seed=n_ac)
+            frames[0, :16, :64] = 77                                     # flat blocks: decided by the exact replay only
+            payload = synth.synthetic_bits(batch.capacity_bits(f, h, w, n_ac), seed=n_ac)
+            native.check(lib.svs_memset(d_cnt, 0, 8, None), "memset")
+            native.check(lib.svs_stream_synchronize(None), "sync")
+            lib.svs_guard_counter_set(d_cnt)
+            try:
+                stego, used = batch.embed_frames(frames, delta, n_ac, payload, mode="guarded")
+            finally:
+                lib.svs_guard_counter_set(None)
+            redone = np.zeros(1, np.uint64)
+            native.check(lib.svs_memcpy_d2h(redone.ctypes.data, d_cnt, 8, None), "d2h")
+            native.check(lib.svs_stream_synchronize(None), "sync")
+            ref, ref_used = orc.batch_embed(frames, delta, payload, n_ac)
+            assert used == ref_used and np.array_equal(stego, ref), (n_ac, "stego differs from the oracle")
+            packed, n_bits = batch.extract_frames(stego, delta, n_ac, mode="guarded")
+            assert np.array_equal(np.unpackbits(packed, count=n_bits), orc.batch_extract_bits(stego, delta, n_ac)), n_ac
+            out.append((int(redone[0]), stego.tobytes(), packed.tobytes()))
+        return out
+
+    plain = run()
+    assert plain[0][0] > 0 and plain[1][0] > 0            # the guard really sends blocks to the exact replay
+    for name, value in (("SVS_GUARD_SCALE", "0"), ("SVS_GUARDED_OFF", "1"), ("SVS_GUARDED2_OFF", "1"), ("SVS_FAST_MAX_ROWS", "0"),
+                        ("SVS_EXACT_BPL", "2"), ("SVS_FIXED_N", "0"), ("SVS_EXTRACT_SHUFFLE", "1"), ("SVS_FAST_EXTRACT_U1", "1"),
+                        ("SVS_EMBED_BPL", "1"), ("SVS_EXTRACT_BPL", "2"), ("SVS_EMBED_XCD_CHUNK", "7"), ("SVS_EXTRACT_XCD_CHUNK", "5"),
+                        ("SVS_EMBED_WG_PER_CU", "2"), ("SVS_EXTRACT_WG_PER_CU", "2")):
+        monkeypatch.setenv(name, value)
+    assert run() == plain
+    native.check(lib.svs_free(d_cnt), "free")

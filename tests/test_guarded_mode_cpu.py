@@ -13,7 +13,8 @@ import numpy as np
 import pytest
 from hypothesis import given, settings, strategies as st
 
-from testlib import (CSRC, GUARDED_POINTS, guarded_soak_cases, REPO, case_inputs, emu_embed, sha, single_frame_cases, structured_covers)
+from testlib import (CSRC, GUARDED_POINTS, guarded_soak_cases, REPO, case_inputs, emu_embed, hostemu, sha, single_frame_cases,
+                     structured_covers)
 from oracle import qim_dct_oracle as orc
 from svsdct import synth
 
@@ -170,3 +171,47 @@ def test_random_geometries_steps_and_budgets_equal_the_oracle():
         ref, ref_used = orc.batch_embed(frames, delta, bits[off:off + n_bits], n_ac)
         assert used == ref_used == min(n_bits, cap), (it, used, ref_used)
         assert np.array_equal(got, ref), (it, frames.shape, n_ac, delta, int((got != ref).sum()))
+
+
+def test_packed_vertical_pass_is_pocketfft_bit_for_bit():
+    """Round 4: rows 0 and 1 of the vertical pass of the two-row guarded kernel are formed from exact integer first stages on
+    packed 16-bit lanes (svs::vertical_pf01_packed).  They must be the float32 values scipy's own column transform gives -
+    every quantiser decision downstream rests on it - on random, extreme, flat and one-hot columns."""
+    from scipy.fftpack import dct
+    lib = hostemu()
+    rng = np.random.default_rng(31)
+    blocks = [rng.integers(0, 256, (8, 8)) for _ in range(20000)]
+    blocks += [rng.choice([0, 255], (8, 8)) for _ in range(4000)] + [rng.integers(0, 4, (8, 8)) for _ in range(1000)]
+    blocks += [rng.integers(252, 256, (8, 8)) for _ in range(1000)] + [np.full((8, 8), v) for v in (0, 1, 127, 128, 254, 255)]
+    for y in range(8):
+        for v in (1, 255):
+            b = np.zeros((8, 8), np.int64)
+            b[y, :] = v
+            blocks.append(b)
+    blk = np.ascontiguousarray(np.stack(blocks), np.uint8)
+    want = dct(blk.astype(np.float32), axis=1, norm="ortho")[:, :2, :]           # [block, u, x], float32 (pocketfft)
+    assert want.dtype == np.float32
+    got = np.zeros(17, np.float32)
+    for i in range(len(blk)):
+        lib.emu_vertical_pf01(blk[i].ctypes.data, got.ctypes.data)
+        assert np.array_equal(got[:16].view(np.uint32).reshape(2, 8) & 0x7fffffff, want[i].view(np.uint32) & 0x7fffffff) and \
+            np.array_equal(got[:16].reshape(2, 8), want[i]), i                    # equal values (the sign of a zero is free)
+        assert int(got[16]) == int(blk[i].sum())
+
+
+def test_float_domain_quantiser_step_equals_the_integer_form():
+    """qim_change (round 4: rounding by the 1.5 * 2^23 constant, parity forced on the bit pattern) against
+    q = int(round(c / delta)), q' = q with its low bit replaced, float(q' * delta) - c, for every kind of step"""
+    lib = hostemu()
+    rng = np.random.default_rng(8)
+    for delta in [8, 0.25, 0.5, 2, 20, 1, 3, 7, 7.5, 13, 100, 0.3, 1000.5, 4096, 0.1 + 0.2, 33.3]:
+        parts = [rng.uniform(-2100, 2100, 400_000).astype(np.float32),
+                 (rng.integers(-16320, 16321, 200_000) / 8.0).astype(np.float32)]
+        k = np.arange(-3000, 3000, dtype=np.float64)
+        ties = ((k + 0.5) * delta).astype(np.float32)
+        ties = ties[np.abs(ties) <= 2100]
+        parts += [ties, np.nextafter(ties, np.float32(np.inf)), np.nextafter(ties, np.float32(-np.inf)),
+                  np.float32([0.0, -0.0, 1e-30, -1e-30, 1e-45, 2040.0, -2040.0])]
+        c = np.ascontiguousarray(np.concatenate(parts))
+        bit = rng.integers(0, 2, c.size).astype(np.uint8)
+        assert lib.emu_qim_change_mismatches(c.ctypes.data, bit.ctypes.data, c.size, float(delta)) == 0, delta

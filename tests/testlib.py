@@ -56,17 +56,48 @@ def structured_covers(h, w, seed=0):
         "abba_stripes": np.repeat(abba[None], h, axis=0),
         "lsb_noise_on_flat": (100 + rng.integers(0, 2, (h, w))).astype(np.uint8),
         "outer_product_blocks": outer.clip(0, 255).astype(np.uint8),
+        # smooth content: every block of a ramp has the SAME AC coefficients, a zero-heavy payload
+        # requantises them to 0 and the block comes out flat at its mean - on the integer grid in 1 block of 8
+        "horizontal_ramp": np.clip(np.rint(xx * 255.0 / (w - 1)), 0, 255).astype(np.uint8),
+        "vertical_ramp": np.clip(np.rint(yy * 255.0 / (h - 1)), 0, 255).astype(np.uint8),
+        "diagonal_ramp": np.clip(np.rint((xx + yy) * 255.0 / (w + h - 2)), 0, 255).astype(np.uint8),
+        "slow_sinusoid": np.clip(np.rint(128 + 90 * np.sin(xx / 97.0) * np.cos(yy / 61.0)), 0, 255).astype(np.uint8),
+        "gaussian_sigma1_on_128": np.clip(np.rint(128 + rng.normal(0, 1.0, (h, w))), 0, 255).astype(np.uint8),
+        "near_black_0_1": rng.integers(0, 2, (h, w), dtype=np.uint8),
     }
+
+
+SMOOTH_COVERS = ("horizontal_ramp", "vertical_ramp", "diagonal_ramp", "slow_sinusoid", "gaussian_sigma1_on_128", "near_black_0_1")
+
+
+def contract_payloads(n_bits, seed):
+    """name -> payload of the FAST contract checks: Bernoulli(1/2) - under which 'all of a block's bits are 0' has
+    probability 2^-n and is never seen at n >= 8 -, all zero, and 1 % ones: the reference's real stream opens with a
+    976-bit header full of zero bytes (embed_process.py:62-74), and a block whose bits are all 0 has every near-zero
+    coefficient requantised to exactly 0."""
+    rng = np.random.default_rng(seed)
+    return {"bernoulli_half": synth.synthetic_bits(n_bits, seed=seed),
+            "all_zero": np.zeros(n_bits, np.uint8),
+            "one_percent_ones": (rng.random(n_bits) < 0.01).astype(np.uint8)}
 
 
 ORIGINAL_COVERS = ("natural_like", "flat_128", "constant_rows", "constant_columns", "half_letterbox", "checker_8", "ramp")
 
 # (n_ac, delta) points of the FAST-mode contract checks on structured content (VERDICT r01 next #1) plus the settings at
 # which the index-4 / two-row coincidences are largest; (1, 8), (16, 8), (36, 8), (63, 4) added after VERDICT r02 next #3
-CONTRACT_POINTS = [(3, 8), (3, 16), (7, 4), (10, 20), (4, 8), (8, 4), (8, 2), (1, 8), (16, 8), (36, 8), (63, 4), (9, 8)]
+CONTRACT_POINTS = [(3, 8), (3, 16), (7, 4), (10, 20), (4, 8), (8, 4), (8, 2), (1, 8), (16, 8), (36, 8), (63, 4), (9, 8),
+                   # VERDICT r03 next #1: large steps at n >= 8 (the GUI offers delta 1..100, app.py:232)
+                   (8, 20), (10, 64), (11, 64), (15, 100), (16, 64), (63, 64)]
 # (n_ac, delta) points of the GUARDED-mode identity checks (one and two coefficient rows; the ends of the delta range included)
 GUARDED_POINTS = [(3, 8), (1, 8), (7, 4), (4, 8), (3, 16), (5, 0.5), (2, 0.25), (3, 100), (7, 4096), (6, 7.3),
                   (10, 8), (8, 4), (15, 20), (12, 0.5), (9, 100), (10, 4096)]
+
+
+def psnr_gap(a, b):
+    """|a - b| in dB; 0 when both are infinite (stego == cover in both: nothing was changed)"""
+    if np.isinf(a) or np.isinf(b):
+        return 0.0 if a == b else float("inf")
+    return abs(a - b)
 
 
 def sha(a):
@@ -150,6 +181,9 @@ def hostemu():
     lib.emu_pf_dct3.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
     lib.emu_forward_block.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
     lib.emu_idct8.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    lib.emu_vertical_pf01.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    lib.emu_qim_change_mismatches.restype = ctypes.c_uint64
+    lib.emu_qim_change_mismatches.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_double]
     lib.emu_quant_mismatches.restype = ctypes.c_uint64
     lib.emu_quant_mismatches.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_double]
     _EMU = lib

@@ -16,14 +16,15 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--frames", type=int, default=600); ap.add_argument("--rounds", type=int, default=15)
 ap.add_argument("--n-ac", type=int, default=3); ap.add_argument("--delta", type=float, default=8.0)
 ap.add_argument("--h", type=int, default=2160); ap.add_argument("--w", type=int, default=3840)
-ap.add_argument("--mode", default="fast", choices=["fast", "exact"])
+ap.add_argument("--mode", default="fast", choices=["fast", "guarded", "exact"])
 ap.add_argument("--extract-u1-ab", action="store_true", help="A/B SVS_FAST_EXTRACT_U1=0 vs 1 on the first lib")
 ap.add_argument("--fixed-n-ab", action="store_true", help="A/B SVS_FIXED_N=1 vs 0 on the first lib")
 ap.add_argument("--chunks", default="", help="comma list: sweep SVS_*_XCD_CHUNK on the first lib")
-ap.add_argument("--env-sweep", default="", help="NAME=v1,v2,...: sweep one environment knob on the first lib")
+ap.add_argument("--env-sweep", default="", help="NAME=v1,v2,...: sweep one environment knob on the first lib - which must be "
+                "lib/variants/libsvsdct_exp.so (make -C csrc exp): the product library reads no environment variable")
 ap.add_argument("libs", nargs="+")
 a = ap.parse_args()
-FLAGS = 1 if a.mode == "exact" else 0
+FLAGS = {"fast": 0, "exact": 1, "guarded": 2}[a.mode]       # SVS_EXACT_POCKETFFT = 1, SVS_EXACT_GUARDED = 2
 
 def load(path):
     lib = C.CDLL(os.path.abspath(path))

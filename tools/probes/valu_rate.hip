@@ -29,6 +29,40 @@ __global__ __launch_bounds__(64) void probe(float *out, unsigned long long *cycl
             else if constexpr (KIND == 7) asm volatile("v_pk_add_u16 %0, %0, %1" : "+v"(a[i]) : "v"(c1));
             else if constexpr (KIND == 8) asm volatile("v_floor_f32 %0, %0" : "+v"(a[i]));
             else if constexpr (KIND == 9) asm volatile("v_add_u32 %0, %0, %1" : "+v"(a[i]) : "v"(c1));
+            // round 4: the instruction kinds of the guarded two-row embed kernel's phase 1
+            else if constexpr (KIND == 10) asm volatile("v_fract_f32 %0, %0" : "+v"(a[i]));
+            else if constexpr (KIND == 11) asm volatile("v_rndne_f32 %0, %0" : "+v"(a[i]));
+            else if constexpr (KIND == 12) asm volatile("v_min_f32 %0, %0, %1" : "+v"(a[i]) : "v"(c1));
+            else if constexpr (KIND == 13) asm volatile("v_min3_f32 %0, %0, |%1|, |%2|" : "+v"(a[i]) : "v"(c1), "v"(c2));
+            else if constexpr (KIND == 14) asm volatile("v_and_b32 %0, %0, %1" : "+v"(a[i]) : "v"(c1));
+            else if constexpr (KIND == 15) asm volatile("v_bfe_u32 %0, %0, 8, 8" : "+v"(a[i]));
+            else if constexpr (KIND == 16) asm volatile("v_perm_b32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(c1), "v"(c2));
+            else if constexpr (KIND == 17) asm volatile("v_cvt_pk_u8_f32 %0, %1, 1, %0" : "+v"(a[i]) : "v"(c1));
+            else if constexpr (KIND == 18) asm volatile("v_cvt_f32_i32 %0, %0" : "+v"(a[i]));
+            else if constexpr (KIND == 19) asm volatile("v_cvt_i32_f32 %0, %0" : "+v"(a[i]));
+            else if constexpr (KIND == 20) asm volatile("v_pk_sub_i16 %0, %0, %1" : "+v"(a[i]) : "v"(c1));
+            else if constexpr (KIND == 21) asm volatile("v_dot4_u32_u8 %0, %1, %2, %0" : "+v"(a[i]) : "v"(c1), "v"(c2));
+            else if constexpr (KIND == 22) asm volatile("v_bfi_b32 %0, %1, %2, %0" : "+v"(a[i]) : "v"(c1), "v"(c2));
+            else if constexpr (KIND == 23) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[i]) : "v"(c1));
+            else if constexpr (KIND == 24) asm volatile("v_cmp_lt_f32 vcc, %0, %1" :: "v"(a[i]), "v"(c1) : "vcc");
+            else if constexpr (KIND == 25) asm volatile("v_sub_f32 %0, |%0|, %1" : "+v"(a[i]) : "v"(c1));
+            else if constexpr (KIND == 26) asm volatile("v_cvt_f32_i32_sdwa %0, sext(%0) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1" : "+v"(a[i]));
+            else if constexpr (KIND == 27) asm volatile("v_lshrrev_b32 %0, 8, %0" : "+v"(a[i]));
+            else if constexpr (KIND == 28) asm volatile("v_and_or_b32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(c1), "v"(c2));
+            else if constexpr (KIND == 29) asm volatile("v_max_f32 %0, |%0|, |%1|" : "+v"(a[i]) : "v"(c1));
+            else if constexpr (KIND == 30) asm volatile("v_sub_u32 %0, %0, %1" : "+v"(a[i]) : "v"(c1));
+            else if constexpr (KIND == 31) asm volatile("v_add3_u32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(c1), "v"(c2));
+            else if constexpr (KIND == 32) asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(a[i]) : "v"(c1), "v"(c2));
+            else if constexpr (KIND == 33) asm volatile("v_mad_u32_u24 %0, %0, %1, %2" : "+v"(a[i]) : "v"(c1), "v"(c2));
+            else if constexpr (KIND == 34) asm volatile("v_cvt_flr_i32_f32 %0, %0" : "+v"(a[i]));
+            else if constexpr (KIND == 35) asm volatile("v_pk_fma_f16 %0, %0, %1, %2" : "+v"(a[i]) : "v"(c1), "v"(c2));
+            else if constexpr (KIND == 36) asm volatile("v_med3_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(c1), "v"(c2));
+            else if constexpr (KIND == 37) asm volatile("v_xor_b32 %0, %0, %1" : "+v"(a[i]) : "v"(c1));
+            else if constexpr (KIND == 38) asm volatile("v_lshl_or_b32 %0, %0, 8, %1" : "+v"(a[i]) : "v"(c1));
+            else if constexpr (KIND == 39) asm volatile("v_cvt_f32_u32 %0, %0" : "+v"(a[i]));
+            else if constexpr (KIND == 40) asm volatile("v_pk_add_i16 %0, %0, %1" : "+v"(a[i]) : "v"(c1));
+            else if constexpr (KIND == 41) asm volatile("v_sad_u8 %0, %0, %1, %2" : "+v"(a[i]) : "v"(c1), "v"(c2));
+            else if constexpr (KIND == 42) asm volatile("v_mov_b32 %0, %1" : "+v"(a[i]) : "v"(c1));
         }
     }
     const unsigned long long t1 = __builtin_readcyclecounter();
@@ -41,7 +75,7 @@ __global__ __launch_bounds__(64) void probe(float *out, unsigned long long *cycl
 template <int KIND>
 void run(const char *name, int cus) {
     printf("%-16s", name);
-    for (int waves_per_simd : {1, 2, 3, 4, 6, 8}) {
+    for (int waves_per_simd : {2, 4, 8}) {
         const int blocks = cus * 4 * waves_per_simd;          // 64-thread workgroups: one wave each
         float *out; unsigned long long *cyc;
         hipMalloc(&out, sizeof(float) * 64 * blocks);
@@ -68,5 +102,14 @@ int main() {
     run<0>("v_add_f32", cus); run<1>("v_fma_f32", cus); run<5>("v_mul_f32", cus); run<2>("v_pk_add_f32", cus);
     run<3>("v_pk_fma_f32", cus); run<4>("v_pk_mul_f32", cus); run<6>("v_cvt_f32_ubyte0", cus); run<7>("v_pk_add_u16", cus);
     run<8>("v_floor_f32", cus); run<9>("v_add_u32", cus);
+    run<10>("v_fract_f32", cus); run<11>("v_rndne_f32", cus); run<12>("v_min_f32", cus); run<13>("v_min3_f32 |.|", cus);
+    run<14>("v_and_b32", cus); run<15>("v_bfe_u32", cus); run<16>("v_perm_b32", cus); run<17>("v_cvt_pk_u8_f32", cus);
+    run<18>("v_cvt_f32_i32", cus); run<19>("v_cvt_i32_f32", cus); run<20>("v_pk_sub_i16", cus); run<21>("v_dot4_u32_u8", cus);
+    run<22>("v_bfi_b32", cus); run<23>("v_cndmask_b32", cus); run<24>("v_cmp_lt_f32", cus); run<25>("v_sub_f32 |.|", cus);
+    run<26>("v_cvt_f32_i32 sdwa", cus); run<27>("v_lshrrev_b32", cus); run<28>("v_and_or_b32", cus); run<29>("v_max_f32 |.|", cus);
+    run<30>("v_sub_u32", cus); run<31>("v_add3_u32", cus); run<32>("v_fmac_f32", cus); run<33>("v_mad_u32_u24", cus);
+    run<34>("v_cvt_flr_i32_f32", cus); run<35>("v_pk_fma_f16", cus); run<36>("v_med3_f32", cus); run<37>("v_xor_b32", cus);
+    run<38>("v_lshl_or_b32", cus); run<39>("v_cvt_f32_u32", cus); run<40>("v_pk_add_i16", cus); run<41>("v_sad_u8", cus);
+    run<42>("v_mov_b32", cus);
     return 0;
 }
