@@ -338,6 +338,7 @@ struct QimParams {
     double delta_d;     // delta         - multiplier when (double)delta_f != delta (QM_DOUBLE)
     float tie_slope;    // FAST extraction: c00 * tie_slope bounds |c_fast/delta - c_pocketfft/delta| (see TIE_SLOPE)
     float tie2_sum, tie2_resid, tie2_c00;   // ... and its per-block refinement (SVS_TIE2_*), all per unit of 1/delta
+    float tie2_max;                         // the largest value that margin takes over all blocks (any pixel sum)
     // GUARDED embed (embed_block_guarded): BETA = g_sum * (sum of pixels) + g_resid * sqrt(64 sum p^2 - (sum p)^2) + g_delta
     float g_sum, g_resid, g_delta;
 };
@@ -361,6 +362,7 @@ struct QimParams {
 // 4x tighter than the global slope at mean 128 (3.5e-3 -> never-embedded noise: 0.7 % of the blocks at n = 10, delta = 8
 // instead of 4 %).  Flat index 4 does not enter: its value is pocketfft's own (pf_row0_coefficient4).
 // Constants of the largest row count (U = 8; U = 2: KE 24.3):
+#define SVS_FAST_EXTRACT_DELTA_MIN 0x1p-10   // below, |c / delta| can reach 2^22 and extract_block_cheap's rounding constant no longer rounds: exact kernels
 #define SVS_TIE2_KDC 64.0001
 #define SVS_TIE2_KE 25.92
 
@@ -412,6 +414,18 @@ SVS_HD void payload_window(const uint32_t *bits, uint32_t n_words, uint64_t s, u
     hi = (uint32_t)((a << sh) >> 32);
     lo = (uint32_t)((b << sh) >> 32);
 }
+
+// n <= 15 (one and two coefficient rows): a block's window - and the windows of two adjacent blocks, 2 n <= 30 bits - lies
+// inside the 64 stream bits that start at the dword holding stream bit s: two loads instead of three per block (six per lane
+// with two blocks per lane).  payload_qword returns those 64 bits, MSB first; window32 the 32 stream
+// bits starting `sh` bits in (sh < 32 for the block at s, < 47 for its right neighbour).
+SVS_HD uint64_t payload_qword(const uint32_t *bits, uint32_t n_words, uint64_t s) {
+    const uint32_t wi = (uint32_t)(s >> 5);
+    const uint32_t w0 = __builtin_bswap32(wi < n_words ? bits[wi] : 0u);
+    const uint32_t w1 = __builtin_bswap32(wi + 1 < n_words ? bits[wi + 1] : 0u);
+    return ((uint64_t)w0 << 32) | w1;
+}
+SVS_HD uint32_t window32(uint64_t q, uint32_t sh) { return (uint32_t)((q << sh) >> 32); }
 
 // bit i (0 = first) of the 64-bit MSB-first window hi:lo
 SVS_HD uint32_t window_bit(uint32_t hi, uint32_t lo, int i) {
@@ -558,45 +572,83 @@ SVS_HD float guard_sqrt(float v) {   // any sqrt accurate to a few ulp will do: 
 #endif
 }
 
-// Parity bits of round(c_k/delta), k = 1..n, MSB-first into hi:lo (config_and_setup.py:160-161).
-// Returns true when some c_k/delta is so close to a rounding tie that the reference's own float32 coefficients could
-// round the other way (see SVS_TIE_SLOPE): the caller must then redo the block with extract_block_exact.  When it returns
-// false the bits ARE the reference's, so the quantiser needs no division here: t = c * (1/delta) is within the band of
-// fl(c_pf / delta) as well.
+// FAST extraction with two and more coefficient rows, in two steps (round 4).
+//
+// extract_block_cheap: parity bits of round(c_k/delta), k = 1..n, MSB-first into hi:lo (config_and_setup.py:160-161), from the
+// FMA-factored forward transform.  t + 1.5 * 2^23 rounds t = c * (1/delta) to the nearest-even integer q and leaves q in the
+// low mantissa bits of the sum (|t| < 2^22: the host routes delta < 2^-10 to the exact kernels), so the parity is bit 0 of the
+// sum's pattern and one v_alignbit_b32 per coefficient - taken in DESCENDING order - shifts it into place: no rndne, no
+// conversion, no shift / or (three 1.6-slot instructions per coefficient before, profiles/r04_valu_issue_rate.txt).
+// Returns true when the block is a CANDIDATE: some t lies within qp.tie2_max - the largest value the per-block margin below
+// can take for any block - of a rounding tie.  A block that is not a candidate has the reference's bits (the margin bounds
+// |c_fast - c_pocketfft| / delta for EVERY coefficient, flat index 4 included: tools/guard_bound.py --tie), and needs nothing
+// else; stego frames at delta >= 8 have no candidates at all (their coefficients sit within 4 / delta of the quantiser grid),
+// so a wave of the kernel skips step two after one ballot.
+// extract_block_settle (waves with a candidate; every lane of such a wave): what round 3 computed for every block - flat
+// index 4 exactly as pocketfft has it (for integer pixels it is a multiple of 1/8: c / delta sits EXACTLY on a tie in 1 block of
+// 8 delta, SURVEY N6, and only the reference's own float32 sequence says which way it falls; its bit is replaced), and the
+// per-block margin  u' (KDC mean + KE ||X - mean||_2) / delta  from the pixel sum alone (see SVS_TIE2_*).  Returns true when
+// a coefficient other than 4 is inside the margin of a tie: the caller then redoes the block with the pocketfft-identical
+// transform (8 lanes per block on the device, extract_block_exact on the host emulation).  For a non-candidate block the
+// result is false and the bits do not change - by the bound - so taking step two per wave (device) or per block (host
+// emulation) gives the same stream.
 template <int U, int QM, int NFIX = 0>
-SVS_HD bool extract_block(const uint32_t (&rx)[8], const uint32_t (&ry)[8], uint32_t n_rt, const QimParams &qp,
-                          uint32_t &hi, uint32_t &lo) {
+SVS_HD bool extract_block_cheap(const uint32_t (&rx)[8], const uint32_t (&ry)[8], uint32_t n_rt, const QimParams &qp,
+                                uint32_t &hi, uint32_t &lo, float &off) {
     const uint32_t n = NFIX ? (uint32_t)NFIX : n_rt;
     float D[U][8];
-    ForwardSide side;
-    forward_rows<U>(rx, ry, D, &side);
+    forward_rows<U>(rx, ry, D);
     hi = 0;
     lo = 0;
-    float off = 0.0f;  // largest |t - round(t)| over the used coefficients (0.5 = exactly on a tie)
+    off = 0.0f;        // largest |t - round(t)| over the used coefficients other than flat index 4 (0.5 = exactly on a tie)
+    float d4 = 0.0f;   // t - round(t) of flat index 4
+    const float kMagic = 12582912.0f;   // 1.5 * 2^23
 #pragma unroll
-    for (int k = 1; k < 8 * U; ++k) {
+    for (int k = 8 * U - 1; k >= 1; --k) {
         if ((uint32_t)k <= n) {  // wave-uniform
-            float r;
-            if (k == 4) {   // pocketfft's own coefficient: its ties (1 block in 8 delta) are settled here, not redone
-                r = (float)quant_index<QM>(side.c4, qp);
-            } else {
-                const float t = D[k >> 3][k & 7] * qp.inv_delta_f;
-                r = rintf(t);
-                off = fmaxf(off, fabsf(t - r));
-            }
-            const uint32_t bit = (uint32_t)(int)r & 1u;
-            const int i = k - 1;
-            if (i < 32) hi |= bit << ((31 - i) & 31);
-            else lo |= bit << ((63 - i) & 31);
+            const float t = D[k >> 3][k & 7] * qp.inv_delta_f;
+            const float m = t + kMagic;
+            const float d = t - (m - kMagic);
+            if (k == 4) d4 = d;
+            else off = fmaxf(off, fabsf(d));
+            const uint32_t mb = __builtin_bit_cast(uint32_t, m);
+            if (k - 1 < 32) hi = (mb << 31) | (hi >> 1);   // v_alignbit_b32: bit of coefficient i ends at 31 - i
+            else lo = (mb << 31) | (lo >> 1);
         }
     }
-    // |t| beyond 2^23 has no fractional part (off == 0) and no tie; NaN cannot occur (finite pixels, delta > 0).
+    return !(fmaxf(off, fabsf(d4)) < 0.5f - qp.tie2_max);
+}
+
+template <int QM>
+SVS_HD bool extract_block_settle(const uint32_t (&rx)[8], const uint32_t (&ry)[8], uint32_t n, const QimParams &qp, uint32_t &hi,
+                                 float off) {
+    float a0[4], b0[4], V0[8];
+    vertical_u1_packed(rx, a0);      // row 0 of the vertical pass: fl(colsum * a(0)) - pocketfft's own values
+    vertical_u1_packed(ry, b0);
+#pragma unroll
+    for (int x = 0; x < 4; ++x) { V0[x] = a0[x]; V0[4 + x] = b0[x]; }
+    ForwardSide side;
+    forward_side(V0, &side);
+    if (n >= 4) {
+        const uint32_t bit = (uint32_t)quant_index<QM>(side.c4, qp) & 1u;
+        hi = (hi & ~(1u << 28)) | (bit << 28);   // i = 3 -> bit 31 - 3
+    }
     // The per-block bound wants S = sum of the pixels and their energy Q = sum p^2 through 64 Q - S^2; pixels are at most
     // 255, so Q <= 255 S and 64 Q - S^2 <= S (16320 - S): no pass over the pixels (S = the vertical pass's DC row summed, over a(0)).
     const float S = side.v0_sum * (1.0000005f / SVS_A0);
     const float spread = guard_sqrt(fmaxf(S * (16320.0f - S), 0.0f)) * 1.000001f;
-    const float margin = fmaf(qp.tie2_sum, S, fmaf(qp.tie2_resid, spread, fmaf(D[0][0], qp.tie2_c00, 0x1p-20f)));
+    const float c00 = side.v0_sum * (SVS_A0 * 1.000001f);     // the DC coefficient (a few roundings from fdct8's own value)
+    const float margin = fmaf(qp.tie2_sum, S, fmaf(qp.tie2_resid, spread, fmaf(c00, qp.tie2_c00, 0x1p-20f)));
     return off >= 0.5f - margin;
+}
+
+// both steps for one block (host emulation; the kernels put a wave ballot between them)
+template <int U, int QM, int NFIX = 0>
+SVS_HD bool extract_block(const uint32_t (&rx)[8], const uint32_t (&ry)[8], uint32_t n_rt, const QimParams &qp,
+                          uint32_t &hi, uint32_t &lo) {
+    float off;
+    if (!extract_block_cheap<U, QM, NFIX>(rx, ry, n_rt, qp, hi, lo, off)) return false;
+    return extract_block_settle<QM>(rx, ry, NFIX ? (uint32_t)NFIX : n_rt, qp, hi, off);
 }
 
 // =====================================================================================================
@@ -1306,6 +1358,15 @@ inline int make_qim(double delta, QimParams *qp) {
         qp->tie2_sum = (float)(ueff * SVS_TIE2_KDC / 64.0 * up);
         qp->tie2_resid = (float)(ueff * SVS_TIE2_KE / 8.0 * up);
         qp->tie2_c00 = (float)(8.0 * 5.9604644775390625e-8 * up);   // the roundings of the quantiser input itself, |c| <= 2 c00
+        // upper bound of extract_block_settle's margin over every pixel sum S in [0, 16320] (scan + slack for the scan step,
+        // the float evaluation and the two 1.000001 factors)
+        double worst = 0.0;
+        for (int S = 0; S <= 16320; S += 8) {
+            const double m = (double)qp->tie2_sum * S + (double)qp->tie2_resid * sqrt((double)S * (16320.0 - S)) +
+                             (double)qp->tie2_c00 * S / 8.0 + 0x1p-20;
+            if (m > worst) worst = m;
+        }
+        qp->tie2_max = (float)(worst * 1.001);
     }
     qp->g_sum = qp->g_resid = qp->g_delta = 0.0f;   // make_guard
     if ((double)qp->delta_f != delta) return QM_DOUBLE;

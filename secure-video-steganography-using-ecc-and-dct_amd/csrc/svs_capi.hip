@@ -272,11 +272,20 @@ int launch_embed_exact(int qm, uint64_t total, hipStream_t st, const uint8_t *gr
     return SVS_OK;
 }
 
+#ifndef SVS_EXTRACT_EXACT_BPL
+#define SVS_EXTRACT_EXACT_BPL 2   // blocks per lane of the one-row pocketfft-identical extract kernel: 2 = 16-byte row loads, medians 0.768 vs 0.806 ms per 600 x 4K and 0.114 vs 0.125 per 300 x 1080p (minima equal; profiles/r04_ab_extract_bpl.txt)
+#endif
 template <int QM>
 int launch_extract_exact(int rows, uint64_t total, hipStream_t st, const uint8_t *gray, const svs::Geometry &g,
-                         const svs::QimParams &qp, uint8_t *out, uint64_t out_bytes) {
-    const dim3 grid((uint32_t)((total + SVS_WG - 1) / SVS_WG));
+                         const svs::QimParams &qp, uint8_t *out, uint64_t out_bytes, bool two_blocks = false) {
     const uint32_t lds_pad = lds_pad_for(knob("SVS_EXTRACT_WG_PER_CU", extract_wg_per_cu(rows)), 4096);
+    if (two_blocks && rows == 1) {
+        const dim3 grid2((uint32_t)((total + 2 * SVS_WG - 1) / (2 * SVS_WG)));
+        hipLaunchKernelGGL((svs::extract_exact_kernel<1, QM, 2>), grid2, dim3(SVS_WG), lds_pad, st, gray, g, qp, out, out_bytes);
+        SVS_HIP(hipGetLastError());
+        return SVS_OK;
+    }
+    const dim3 grid((uint32_t)((total + SVS_WG - 1) / SVS_WG));
 #define SVS_CASE(R)                                                                                                  \
     case R:                                                                                                          \
         hipLaunchKernelGGL((svs::extract_exact_kernel<R, QM>), grid, dim3(SVS_WG), lds_pad, st, gray, g, qp, out, out_bytes); \
@@ -557,6 +566,8 @@ int svs_extract_dev(const uint8_t *d_gray, const svs_planes *planes, double delt
         if (flags & SVS_EXACT_GUARDED)
             flags = (delta >= SVS_GUARD_DELTA_MIN && delta <= SVS_GUARD_DELTA_MAX && knob("SVS_GUARDED_OFF", 0) == 0)   // knob: experiments library only
                         ? 0u : SVS_EXACT_POCKETFFT;
+        // the FAST kernels with two and more rows round c / delta by adding 1.5 * 2^23, which needs |c / delta| < 2^22
+        if ((double)qp.delta_f < SVS_FAST_EXTRACT_DELTA_MIN) flags = SVS_EXACT_POCKETFFT;
         // With one coefficient row (n <= 7) the pocketfft-identical forward transform costs 0.2-3 % (the kernel stays
         // HBM-bound; in-process A/B in profiles/r01_ab_quant_exact.txt), so FAST mode uses it too and extraction is
         // bit-identical to the reference for ANY input frame.  With more rows it costs ~17 % and stays opt-in.
@@ -576,8 +587,10 @@ int svs_extract_dev(const uint8_t *d_gray, const svs_planes *planes, double delt
         } else
 #endif
         if ((flags & SVS_EXACT_POCKETFFT) || (rows == 1 && knob("SVS_FAST_EXTRACT_U1", 0) == 0)) {
-            rc = qm == svs::QM_POW2 ? launch_extract_exact<svs::QM_POW2>(rows, total, st, d_gray, g, qp, d_bits_packed_out, bytes)
-                                    : launch_extract_exact<svs::QM_F32>(rows, total, st, d_gray, g, qp, d_bits_packed_out, bytes);
+            const bool two_x = rows == 1 && knob("SVS_EXTRACT_EXACT_BPL", SVS_EXTRACT_EXACT_BPL) == 2 &&
+                               rows_allow_two_blocks(planes, d_gray, nullptr);
+            rc = qm == svs::QM_POW2 ? launch_extract_exact<svs::QM_POW2>(rows, total, st, d_gray, g, qp, d_bits_packed_out, bytes, two_x)
+                                    : launch_extract_exact<svs::QM_F32>(rows, total, st, d_gray, g, qp, d_bits_packed_out, bytes, two_x);
         } else if (qm == svs::QM_POW2)
             rc = tune.two_blocks ? launch_extract<svs::QM_POW2, 2>(rows, total, st, d_gray, g, qp, d_bits_packed_out, bytes)
                                  : launch_extract<svs::QM_POW2, 1>(rows, total, st, d_gray, g, qp, d_bits_packed_out, bytes);

@@ -269,16 +269,25 @@ __global__ __launch_bounds__(SVS_WG) void extract_kernel(const uint8_t *__restri
     uint32_t hi_a = 0, lo_a = 0, hi_b = 0, lo_b = 0;
     uint32_t ax[8], ay[8], bx[8], by[8];
     bool tie_a = false, tie_b = false;
+    float off_a = 0.0f, off_b = 0.0f;
     if (gblock < g.total_blocks) {
         typename RowVec<BPL>::type v[8];
         load_rows<BPL>(gray + block_offset(gblock, g), g.row_pitch, v);
 #pragma unroll
         for (int r = 0; r < 8; ++r) { ax[r] = v[r].x; ay[r] = v[r].y; }
-        tie_a = extract_block<U, QM, NFIX>(ax, ay, n, qp, hi_a, lo_a);
+        tie_a = extract_block_cheap<U, QM, NFIX>(ax, ay, n, qp, hi_a, lo_a, off_a);      // -> candidate
         if constexpr (BPL == 2) {
 #pragma unroll
             for (int r = 0; r < 8; ++r) { bx[r] = v[r].z; by[r] = v[r].w; }
-            tie_b = extract_block<U, QM, NFIX>(bx, by, n, qp, hi_b, lo_b);
+            tie_b = extract_block_cheap<U, QM, NFIX>(bx, by, n, qp, hi_b, lo_b, off_b);
+        }
+    }
+    // Step two only in waves with a candidate (svs_block.hpp): pocketfft's own flat index 4 and the per-block tie margin.
+    // Stego frames at delta >= 8 have none: one ballot.  (Round 3 computed both for every block: +3..7 % on stego frames.)
+    if (__ballot(tie_a || tie_b) != 0) {
+        if (gblock < g.total_blocks) {
+            tie_a = extract_block_settle<QM>(ax, ay, n, qp, hi_a, off_a);
+            if constexpr (BPL == 2) tie_b = extract_block_settle<QM>(bx, by, n, qp, hi_b, off_b);
         }
     }
     // A quantiser input within the per-block error bound of a rounding tie (svs_block.hpp, SVS_TIE2_*): those blocks get the
@@ -551,13 +560,23 @@ __device__ __forceinline__ bool guard_phase1(uint32_t (&ax)[8], uint32_t (&ay)[8
                                              const QimParams &qp, const uint32_t *__restrict__ bits,
                                              uint64_t bit_offset, uint64_t n_bits, uint32_t n_words,
                                              uint32_t *keep_hi = nullptr) {
-    uint32_t hi, lo;
-    payload_window(bits, n_words, bit_offset + first, hi, lo);
+    uint32_t hi, lo = 0;
+    if constexpr (U <= 2) hi = window32(payload_qword(bits, n_words, bit_offset + first), (uint32_t)((bit_offset + first) & 31u));
+    else payload_window(bits, n_words, bit_offset + first, hi, lo);
     if (keep_hi) *keep_hi = hi;
     const uint32_t nb = block_budget(first, n_bits, n);
     if constexpr (U == 1) return embed_block_guarded<QM>(ax, ay, n, nb, hi, lo, qp);          // n <= 7: rigorous, 8 tests
     else if constexpr (U == 2) return embed_block_guarded2<QM>(ax, ay, n, nb, hi, lo, qp);    // n = 8..15: rigorous, 64 tests
     else return embed_block<U, QM>(ax, ay, n, nb, hi, lo, qp);                                // n >= 16: FAST only
+}
+// the same with the window handed in (two blocks per lane: both windows come from one payload_qword)
+template <int U, int QM>
+__device__ __forceinline__ bool guard_phase1_window(uint32_t (&ax)[8], uint32_t (&ay)[8], uint32_t n, uint64_t first,
+                                                    const QimParams &qp, uint64_t n_bits, uint32_t hi) {
+    static_assert(U <= 2, "n <= 15");
+    const uint32_t nb = block_budget(first, n_bits, n);
+    if constexpr (U == 1) return embed_block_guarded<QM>(ax, ay, n, nb, hi, 0u, qp);
+    else return embed_block_guarded2<QM>(ax, ay, n, nb, hi, 0u, qp);
 }
 
 // what phase 2 needs to rebuild a block's payload window (kept out of the lanes' registers on the common path)
@@ -684,13 +703,16 @@ __device__ __forceinline__ uint32_t guard_phase2_wg(GuardEntry *entries, float *
 #define SVS_KEEP_WINDOW 1
 #endif
 #ifndef SVS_U2_WGPOOL
-#define SVS_U2_WGPOOL 1      // two rows: worklist shared by the workgroup (guard_phase2_wg); 0 = wave-private (A/B)
+#define SVS_U2_WGPOOL 0      // two rows: 1 = worklist shared by the workgroup (guard_phase2_wg): measured SLOWER (2.74 vs 2.65 ms per 600 x 4K, profiles/r04_ab_two_row.txt): the three barriers cost more than the passes saved
 #endif
 #ifndef SVS_GUARD_CAP_WG
 #define SVS_GUARD_CAP_WG 64  // entries of the shared worklist per round (noise content: 33 undecided blocks per workgroup)
 #endif
+#ifndef SVS_U2_MIN_WAVES
+#define SVS_U2_MIN_WAVES 1   // natural allocation (about 100 VGPRs, 4 waves per SIMD)
+#endif
 template <int U>
-constexpr int kEmbedMinWaves = U == 4 ? 4 : 1;
+constexpr int kEmbedMinWaves = U == 4 ? 4 : (U == 2 ? SVS_U2_MIN_WAVES : 1);
 template <int U, int QM, int BPL>
 __global__ __launch_bounds__(SVS_WG, kEmbedMinWaves<U>) void embed_kernel(const uint8_t *gray,
                                                     uint8_t *stego, const Geometry g, const QimParams qp,
@@ -731,10 +753,17 @@ __global__ __launch_bounds__(SVS_WG, kEmbedMinWaves<U>) void embed_kernel(const 
         write = stego != gray;                         // past the budget: byte-identical copy (the reference's loops `break`, :130,:132)
         if (first < n_bits) {
             write = true;
-            und_a = guard_phase1<U, QM>(ax, ay, n, first, qp, bits, bit_offset, n_bits, n_words, KEPT ? &hi_a : nullptr);
-            if constexpr (BPL == 2) {   // a budget of 0 (only the lane the payload ends in can see it) leaves block B as it is
-                if (first + n < n_bits)
-                    und_b = guard_phase1<U, QM>(bx, by, n, first + n, qp, bits, bit_offset, n_bits, n_words, KEPT ? &hi_b : nullptr);
+            if constexpr (BPL == 2) {
+                // both blocks' windows from the two dwords at the lane's first stream bit (2 n <= 14 bits at one row)
+                const uint64_t q = payload_qword(bits, n_words, bit_offset + first);
+                const uint32_t sh = (uint32_t)((bit_offset + first) & 31u);
+                hi_a = window32(q, sh);
+                hi_b = window32(q, sh + n);
+                und_a = guard_phase1_window<U, QM>(ax, ay, n, first, qp, n_bits, hi_a);
+                if (first + n < n_bits)   // a budget of 0 (only the lane the payload ends in can see it) leaves block B as it is
+                    und_b = guard_phase1_window<U, QM>(bx, by, n, first + n, qp, n_bits, hi_b);
+            } else {
+                und_a = guard_phase1<U, QM>(ax, ay, n, first, qp, bits, bit_offset, n_bits, n_words, KEPT ? &hi_a : nullptr);
             }
         }
     }
@@ -760,26 +789,31 @@ __global__ __launch_bounds__(SVS_WG, kEmbedMinWaves<U>) void embed_kernel(const 
     }
 }
 
-template <int U, int QM>
+template <int U, int QM, int BPL = 1>
 __global__ __launch_bounds__(SVS_WG) void extract_exact_kernel(const uint8_t *__restrict__ gray, const Geometry g,
                                                             const QimParams qp, uint8_t *__restrict__ out,
                                                             const uint64_t out_bytes) {
-    __shared__ uint32_t flags[SVS_WG / 64][SVS_WAVE_BITS_DWORDS(1)];
+    __shared__ uint32_t flags[SVS_WG / 64][SVS_WAVE_BITS_DWORDS(BPL)];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t tile = tile_id(g.xcd_chunk);
-    const uint32_t gblock = tile * (uint32_t)SVS_WG + threadIdx.x;
+    const uint32_t gblock = (tile * (uint32_t)SVS_WG + threadIdx.x) * BPL;
     const uint32_t n = g.n_ac;
-    uint32_t hi = 0, lo = 0;
+    uint32_t hi_a = 0, lo_a = 0, hi_b = 0, lo_b = 0;
     if (gblock < g.total_blocks) {
-        typename RowVec<1>::type v[8];
-        load_rows<1>(gray + block_offset(gblock, g), g.row_pitch, v);
+        typename RowVec<BPL>::type v[8];
+        load_rows<BPL>(gray + block_offset(gblock, g), g.row_pitch, v);
         uint32_t ax[8], ay[8];
 #pragma unroll
         for (int r = 0; r < 8; ++r) { ax[r] = v[r].x; ay[r] = v[r].y; }
-        extract_block_exact<U, QM>(ax, ay, n, qp, hi, lo);
+        extract_block_exact<U, QM>(ax, ay, n, qp, hi_a, lo_a);
+        if constexpr (BPL == 2) {   // two adjacent blocks per lane: 16-byte row loads (even block count per row, host-checked)
+#pragma unroll
+            for (int r = 0; r < 8; ++r) { ax[r] = v[r].z; ay[r] = v[r].w; }
+            extract_block_exact<U, QM>(ax, ay, n, qp, hi_b, lo_b);
+        }
     }
-    emit_wave_bits<U, 1>(&flags[wave][0], lane, (uint64_t)tile * (uint32_t)SVS_WG + wave * 64u, n, hi, lo, 0u, 0u, out,
-                         out_bytes);
+    emit_wave_bits<U, BPL>(&flags[wave][0], lane, ((uint64_t)tile * (uint32_t)SVS_WG + wave * 64u) * BPL, n, hi_a, lo_a, hi_b, lo_b,
+                           out, out_bytes);
 }
 
 // ---------------------------------------------------------------------------------------

@@ -212,7 +212,8 @@ uint64_t emu_extract(const uint8_t *gray, int F, int H, int W, double delta, int
         Blk raw;
         raw.load(p, (size_t)W);
         uint32_t hi, lo;
-        if (exact || svs::rows_for(n) == 1) {   // one coefficient row: both modes use the pocketfft-identical forward
+        if (exact || svs::rows_for(n) == 1 || (double)qp.delta_f < SVS_FAST_EXTRACT_DELTA_MIN) {   // as svs_extract_dev routes: one row
+            // and tiny steps use the pocketfft-identical forward in both modes
             if (qm == svs::QM_POW2) svs::extract_block_exact<8, svs::QM_POW2>(raw.x, raw.y, (uint32_t)n, qp, hi, lo);
             else svs::extract_block_exact<8, svs::QM_F32>(raw.x, raw.y, (uint32_t)n, qp, hi, lo);
         } else if (qm == svs::QM_POW2) extract_fast<svs::QM_POW2>(svs::rows_for(n), raw, (uint32_t)n, qp, hi, lo, n_redone);
