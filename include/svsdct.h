@@ -50,32 +50,28 @@ extern "C" {
 #define SVS_ERR_NO_DEVICE (-3)    /* no usable AMD GPU */
 #define SVS_ERR_CAPACITY (-4)     /* an output buffer is too small */
 
-/* `flags` of the embed / extract entry points.
- * All modes run ONE streaming embed kernel shape (csrc/svs_device.hpp): every block goes HBM -> registers -> HBM once,
- * computed with a cheap sparse transform; a block whose result the float32 round-trip noise of the reference's own
- * transform could decide (config_and_setup.py:166-171 transforms every block forth and back and truncates: x - 1e-5
+/* `flags` of the embed / extract entry points.  EVERY value gives the reference's stego pixels and extracted bits, bit for
+ * bit; the flags choose between two kernel families.
+ * The streaming embed kernel (csrc/svs_device.hpp; n_ac <= 15, 0.25 <= delta <= 4096): every block goes HBM -> registers ->
+ * HBM once, computed with a cheap sparse transform; a block whose result the float32 round-trip noise of the reference's
+ * own transform could decide (config_and_setup.py:166-171 transforms every block forth and back and truncates: x - 1e-5
  * becomes x - 1) is "undecided" and is redone INSIDE the kernel with the pocketfft-identical arithmetic (eight lanes per
- * block, LDS worklist private to the wave, or to the workgroup at n_ac = 8..15) - no second launch, no scratch memory, no state kept between calls: every
- * entry point is re-entrant and thread-safe.
- *   0                  FAST.  n_ac <= 15: identical to SVS_EXACT_GUARDED (the same launch; bit-identical to the
- *                      reference).  n_ac >= 16: FMA-factored float32 DCT on the coefficient rows the payload touches;
- *                      EVERY pixel's predicted value is tested and a block is undecided when one lies within 2^-13 of
- *                      an integer (the largest round-trip noise observed on 10^7 blocks of every content class is
- *                      1.3e-4, tools/guard_bound.py --check; an observed figure, not a proven bound - for a guarantee
- *                      pass SVS_EXACT_GUARDED).  Contract for n_ac >= 16: extracted bits exact, stego PSNR within
- *                      0.01 dB of the reference's on the content classes of tests/testlib.py::structured_covers under
- *                      random, all-zero and sparse payloads; pixels can differ where the two forward transforms resolve
- *                      a quantiser near-tie differently.  (Rounds 1-3 had a separate FAST arithmetic for n_ac = 8..15
- *                      that skipped the per-pixel test for "generic" blocks; every review found structured content on
- *                      which the shortcut broke the PSNR contract - last: smooth ramps under a zero-heavy payload,
- *                      +0.68 dB - so it is gone.)  Extraction: bits identical to the reference's for ANY input frame
- *                      (n_ac <= 7: pocketfft-identical transform; n_ac >= 8: a block with a quantiser input within a
- *                      proven error bound of a rounding tie is recomputed with it).
+ * block, LDS worklist private to the wave) - no second launch, no scratch memory, no state kept between calls: every entry
+ * point is re-entrant and thread-safe.  The library reads no environment variable.
+ *   0                  the same launches as SVS_EXACT_GUARDED: bit-identical to the reference.  (Rounds 1-3 had a separate
+ *                      contract-level "FAST" embed arithmetic for n_ac >= 8 behind this value - FMA-factored forward
+ *                      transform, per-pixel grid test skipped for blocks that looked generic.  Every review found structured
+ *                      content on which the shortcut broke the PSNR contract - last: smooth ramps under a zero-heavy
+ *                      payload, +0.68 dB - and with the test on every pixel it was no faster than the bit-identical
+ *                      kernels, so it is gone.)  Extraction: bits identical to the reference's for ANY input frame
+ *                      (n_ac <= 7: pocketfft-identical transform; n_ac >= 8: FMA-factored transform, a block with a
+ *                      quantiser input within a proven error bound of a rounding tie is recomputed with the
+ *                      pocketfft-identical one).
  *   SVS_EXACT_POCKETFFT  every float32 operation of scipy.fftpack.dct/idct(norm='ortho') (pocketfft) is replayed in
  *                      order, on all 64 coefficients of every block, one lane per block: stego pixels, tie decisions
  *                      and the reference's round-trip artefacts are bit-identical to the reference.  About 5x the
- *                      arithmetic of FAST: VALU-bound (0.42 of the HBM roofline).  The yardstick the other modes are
- *                      tested against.
+ *                      arithmetic of the streaming kernel: VALU-bound (0.42 of the HBM roofline).  The yardstick the
+ *                      other kernels are tested against, and what every mode runs for n_ac >= 16.
  *   SVS_EXACT_GUARDED  the same bit-identical result at streaming speed: the kernel computes the payload coefficients
  *                      exactly as pocketfft does (every quantiser decision is the reference's), predicts each stego
  *                      pixel from the sparse inverse of the coefficient changes, and keeps the prediction only where a
@@ -87,9 +83,9 @@ extern "C" {
  *                      (n_ac <= 7: 8 tests per block, 0.05 - 1.7 % of the blocks, 12.5 % of flat ones at n = 3;
  *                      n_ac = 8..15: 64 tests with position-dependent bounds, 1.5 - 13 %).  Applies to n_ac <= 15 and
  *                      0.25 <= delta <= 4096; other calls run the SVS_EXACT_POCKETFFT kernels, so the flag is always
- *                      safe to pass and always bit-identical.  Extraction with this flag runs the FAST kernels (their
- *                      bits are the reference's for any input, see above) inside the same delta range, the
- *                      pocketfft-identical kernels outside it.  Default of the drop-in operator and video pipelines. */
+ *                      safe to pass and always bit-identical.  Extraction with this flag runs the same kernels as
+ *                      flags = 0 inside that delta range, the pocketfft-identical kernels outside it.  Default of the
+ *                      drop-in operator and video pipelines. */
 #define SVS_EXACT_POCKETFFT 1u
 #define SVS_EXACT_GUARDED 2u
 

@@ -461,99 +461,13 @@ SVS_HD float fmin3_abs(float a, float b, float c) {
 #endif
 }
 
-// Embed `nb` (0..n) payload bits, taken MSB-first from hi:lo, into the block held in rx[]/ry[] - FAST arithmetic for THREE AND
-// MORE coefficient rows (n >= 16).  One and two rows (n <= 15) have no separate FAST arithmetic any more: there the rigorous
-// guard (embed_block_guarded / embed_block_guarded2) costs about the same and is bit-identical, so FAST runs it too.
-//
-// Returns true when the block is UNDECIDED and has to be redone with the pocketfft-identical arithmetic (rx/ry then still
-// hold the original pixels: embed_block_exact on the host emulation, the in-kernel replay on the device).
-// Why: the reference transforms every block it enters forth and back (config_and_setup.py:166-171), so its output is
-// trunc(pixel + change + noise) with float32 round-trip noise of up to ~1e-4 (tools/guard_bound.py --check: largest value
-// seen on 10^7 blocks 1.3e-4).  Where pixel + change lies that close to an integer the noise decides the byte - and it does
-// so SYSTEMATICALLY on structured content: untouched flat blocks come out as x - 1, the changes of a flat
-// block (each 0 or +delta) cancel exactly on rows / diagonals, basis +-1/8 of flat indices 4 / 32 / 36 turns a change of 8 k
-// into the integer k, a coefficient that vanishes by exact cancellation of the pixels comes out of this function's forward
-// transform as a 1e-5 residue whose "change" of -1e-5 floors a whole block one level down, a ramp under a zero-heavy payload
-// has all its coefficients deleted and comes out flat at its mean, and the contributions of two EQUAL requantised
-// coefficients (0,1) and (1,0) of a diagonal ramp cancel exactly on the anti-diagonal.
-// EVERY pixel's prediction is therefore tested against the integer grid (SVS_FAST_GUARD = 2^-13, just below the largest
-// round-trip noise ever observed; not a proven bound - that is what GUARDED is for); rounds 2 and 3 skipped the test for
-// blocks that looked "generic" and each review found a content family that the shortcut mistook (exact
-// cancellations, r03: deleted coefficients; round 4's own probe: the diagonal ramp above).  The test is fused with the
-// output computation: the stego rows are built in scratch registers and committed only if the block is decided.
-// What FAST does not reproduce are isolated coincidences inside that guard and quantiser near-ties of the FMA-factored
-// forward transform (both unbiased: PSNR unaffected); GUARDED / EXACT modes do.
-#define SVS_FAST_GUARD 0x1p-13f
-template <int U, int QM>
-SVS_HD bool embed_block(uint32_t (&rx)[8], uint32_t (&ry)[8], uint32_t n, uint32_t nb, uint32_t hi, uint32_t lo,
-                        const QimParams &qp) {
-    static_assert(U >= 3, "n <= 15 runs the rigorous guard (embed_block_guarded / embed_block_guarded2)");
-    float D[U][8];
-    ForwardSide side;
-    forward_rows<U>(rx, ry, D, &side);
-    D[0][4] = side.c4;   // the reference's own value where exact ties are systematic
-
-    // QIM on flat coefficients 1..n: force the parity of round(c/delta) to the payload bit by
-    // +1 (bit 1) / -1 (bit 0), requantise (config_and_setup.py:146-156); keep only the change.
-#pragma unroll
-    for (int k = 0; k < 8 * U; ++k) {
-        const int u = k >> 3, v = k & 7;
-        float change = 0.0f;
-        if (k >= 1 && (uint32_t)k <= n) {  // wave-uniform
-            const int i = k - 1;
-            const int bit = (int)window_bit(hi, lo, i);
-            const float c = D[u][v];
-            int q = quant_index<QM>(c, qp);
-            q = force_parity(q, bit);
-            float cn;
-            if constexpr (QM == QM_DOUBLE) cn = (float)((double)q * qp.delta_d);
-            else cn = (float)q * qp.delta_f;
-            change = cn - c;   // the budget is applied below, for the one block it concerns
-        }
-        D[u][v] = change;
-    }
-    // Budget (config_and_setup.py:130,132,141): only the block the payload ends in has nb < n - its coefficients past the
-    // budget stay as they are.  Kept out of the loop above (a compare and a select per coefficient for every block of the
-    // batch: -2 % at n = 63); on the device it is a branch no lane of an ordinary wave takes.
-    if (nb < n) {
-#pragma unroll
-        for (int k = 1; k < 8 * U; ++k)
-            if ((uint32_t)(k - 1) >= nb) D[k >> 3][k & 7] = 0.0f;
-    }
-
-    // inverse transform of the change: horizontal on the U rows, then vertical per column with U non-zero inputs.
-    // trunc(clip(pixel + change)) == clip(pixel + floor(change)) for an integer pixel (:171); the floor comes from the store's
-    // own rounding: v_cvt_pk_u8_f32 rounds to nearest even, so it is fed pixel + change - (0.5 - 2^-16) - an integer-valued sum
-    // (no change) maps to itself, the offset is exact on the float32 grid of [0, 256) - and a decided pixel (fractional part of
-    // the change at least 2^-13 away from 0 and 1) stores its floor.  The offset enters through the DC input: -(0.5 - 2^-16)/a(0).
-    float P[U][8];
-    idct8<8, true>(D[0], P[0]);
-#pragma unroll
-    for (int u = 1; u < U; ++u) idct8<8, false>(D[u], P[u]);
-    constexpr float kOff = (0.5f - 0x1p-16f) / SVS_A0;
-    constexpr float kMid = 0.5f + 0x1p-16f;    // fract(change - (0.5 - 2^-16)) of a change ON the integer grid
-    float near = 1.0f;   // smallest distance of a predicted change from the integer grid (the pixel itself is an integer)
-    uint32_t nx[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ny[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // the stego rows, committed only if decided
-#define SVS_OUTCOL(X, W, NW, B)                                                                   \
-    {                                                                                             \
-        float in[8] = {0, 0, 0, 0, 0, 0, 0, 0};                                                   \
-        _Pragma("unroll") for (int u = 0; u < U; ++u) in[u] = P[u][X];                            \
-        in[0] -= kOff;                                                                            \
-        float out[8];                                                                             \
-        idct8<U, false>(in, out);                                                                 \
-        _Pragma("unroll") for (int y = 0; y < 8; y += 2)                                          \
-            near = fmin3_abs(near, fract_f32(out[y]) - kMid, fract_f32(out[y + 1]) - kMid);       \
-        _Pragma("unroll") for (int y = 0; y < 8; ++y)                                             \
-            NW[y] = put_pixel_rne<B>(ubyte_to_float<B>(W[y]) + out[y], NW[y]);                    \
-    }
-    SVS_OUTCOL(0, rx, nx, 0) SVS_OUTCOL(1, rx, nx, 1) SVS_OUTCOL(2, rx, nx, 2) SVS_OUTCOL(3, rx, nx, 3)
-    SVS_OUTCOL(4, ry, ny, 0) SVS_OUTCOL(5, ry, ny, 1) SVS_OUTCOL(6, ry, ny, 2) SVS_OUTCOL(7, ry, ny, 3)
-#undef SVS_OUTCOL
-    if (nb > 0 && !(near >= SVS_FAST_GUARD)) return true;   // undecided: the block keeps its original pixels
-#pragma unroll
-    for (int r = 0; r < 8; ++r) { rx[r] = nx[r]; ry[r] = ny[r]; }
-    return false;
-}
+// (Rounds 1-3 had a separate FAST embed arithmetic here - FMA-factored forward transform on the payload rows, per-pixel grid
+// test only for blocks that did not look "generic" - whose contract was "PSNR within 0.01 dB".  Each review found structured
+// content on which the shortcut broke it (r02: exact cancellations, r03: coefficients requantised to 0 on smooth ramps,
+// +0.68 dB), round 4's own probe a third family (two equal coefficients of a diagonal ramp cancelling on the anti-diagonal),
+// and with the test on every pixel the arithmetic was no faster than the bit-identical kernels: n = 63 1.45 ms against the
+// lane-per-block pocketfft kernel's 1.31 per 200 x 4K, n = 8..15 0.88 against the rigorous two-row kernel's 0.87
+// (profiles/r04_*).  It is gone: every embed mode produces the reference's pixels.)
 
 SVS_HD uint32_t dot4_u8(uint32_t a, uint32_t b, uint32_t acc) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -1162,9 +1076,13 @@ SVS_HD float qim_change(float c, uint32_t bit, const QimParams &qp) {
     }
 }
 
-template <int QM>
-SVS_HD bool embed_block_guarded2(uint32_t (&rx)[8], uint32_t (&ry)[8], uint32_t n, uint32_t nb, uint32_t hi, uint32_t lo,
+// NFIX (8..15, or 0 = run-time n): the coefficient count at compile time - the quantiser loop loses its wave-uniform tests,
+// outputs of the row-1 transform that nobody reads and inverse inputs that are known zeros disappear from the code.
+template <int QM, int NFIX = 0>
+SVS_HD bool embed_block_guarded2(uint32_t (&rx)[8], uint32_t (&ry)[8], uint32_t n_rt, uint32_t nb, uint32_t hi, uint32_t lo,
                                  const QimParams &qp) {
+    static_assert(NFIX == 0 || (NFIX >= 8 && NFIX <= 15), "two coefficient rows");
+    const uint32_t n = NFIX ? (uint32_t)NFIX : n_rt;
     float V0[8], V1[8];
     uint32_t S = 0, Q = 0;
     {
@@ -1201,7 +1119,8 @@ SVS_HD bool embed_block_guarded2(uint32_t (&rx)[8], uint32_t (&ry)[8], uint32_t 
     }
     float P0[8], P1[8];
     idct8<8, true>(D0, P0);
-    idct8<8, false>(D1, P1);
+    if constexpr (NFIX == 0) idct8<8, false>(D1, P1);
+    else idct8<NFIX - 7, false>(D1, P1);      // row 1: entries 0..n-8 can be non-zero
     // BETA of the three position classes
     const float spread = guard_sqrt((float)(64u * Q - S * S));
     const float base = fmaf(qp.g_sum, (float)S, qp.g_delta);

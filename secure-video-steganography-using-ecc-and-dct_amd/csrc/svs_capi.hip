@@ -168,23 +168,26 @@ int launch_embed(int rows, uint64_t total, hipStream_t st, const uint8_t *gray, 
                  uint32_t n_words) {
     const dim3 grid((uint32_t)((total + SVS_WG * BPL - 1) / (SVS_WG * BPL)));
     const uint32_t lds_pad = lds_pad_for(knob("SVS_EMBED_WG_PER_CU", embed_wg_per_cu(rows, BPL)), kEmbedLds);
-#define SVS_CASE(R)                                                                                            \
-    case R:                                                                                                    \
-        hipLaunchKernelGGL((svs::embed_kernel<R, QM, BPL>), grid, dim3(SVS_WG), lds_pad, st, gray, stego, g, qp, bits, \
-                           bit_offset, n_bits, n_words, g_guard_counter);                                      \
-        break;
-    if constexpr (BPL == 2) {  // two blocks per lane is only instantiated (and only pays) for one coefficient row
-        switch (rows) {
-            SVS_CASE(1)
-            default: return fail(SVS_ERR_INVALID_ARG, "internal: rows=%d with two blocks per lane", rows);
-        }
-    } else {
-        switch (rows) {
-            SVS_CASE(1) SVS_CASE(2) SVS_CASE(3) SVS_CASE(4) SVS_CASE(5) SVS_CASE(6) SVS_CASE(7) SVS_CASE(8)
-            default: return fail(SVS_ERR_INVALID_ARG, "internal: rows=%d", rows);
+    if constexpr (BPL == 1) {
+        // n = 10 (the reference GUI's default, app.py:69; BASELINE configs[1]) has a compile-time-n instantiation of the two-row kernel
+        if (g.n_ac == 10 && knob("SVS_FIXED_N", 1) != 0) {
+            hipLaunchKernelGGL((svs::embed_kernel<2, QM, 1, 10>), grid, dim3(SVS_WG), lds_pad, st, gray, stego, g, qp, bits, bit_offset,
+                               n_bits, n_words, g_guard_counter);
+            SVS_HIP(hipGetLastError());
+            return SVS_OK;
         }
     }
-#undef SVS_CASE
+    if (rows < 1 || rows > 2 || (BPL == 2 && rows != 1)) return fail(SVS_ERR_INVALID_ARG, "internal: rows=%d, %d blocks per lane", rows, BPL);
+    if constexpr (BPL == 2) {   // two blocks per lane is only instantiated (and only pays) for one coefficient row
+        hipLaunchKernelGGL((svs::embed_kernel<1, QM, 2>), grid, dim3(SVS_WG), lds_pad, st, gray, stego, g, qp, bits, bit_offset, n_bits,
+                           n_words, g_guard_counter);
+    } else if (rows == 1) {
+        hipLaunchKernelGGL((svs::embed_kernel<1, QM, 1>), grid, dim3(SVS_WG), lds_pad, st, gray, stego, g, qp, bits, bit_offset, n_bits,
+                           n_words, g_guard_counter);
+    } else {
+        hipLaunchKernelGGL((svs::embed_kernel<2, QM, 1>), grid, dim3(SVS_WG), lds_pad, st, gray, stego, g, qp, bits, bit_offset, n_bits,
+                           n_words, g_guard_counter);
+    }
     SVS_HIP(hipGetLastError());
     return SVS_OK;
 }
@@ -316,16 +319,14 @@ int launch_embed_bgr(int rows, uint64_t total, hipStream_t st, const uint8_t *in
         hipLaunchKernelGGL((svs::embed_bgr_kernel<8, QM, true>), grid, dim3(SVS_WG), lds_pad, st, in, out, ref, g, c, qp, bits,
                            bit_offset, n_bits, n_words);
     } else {
-#define SVS_CASE(R)                                                                                                   \
-    case R:                                                                                                           \
-        hipLaunchKernelGGL((svs::embed_bgr_kernel<R, QM, false>), grid, dim3(SVS_WG), lds_pad, st, in, out, ref, g, c, qp, bits, \
-                           bit_offset, n_bits, n_words);                                                              \
-        break;
-        switch (rows) {
-            SVS_CASE(1) SVS_CASE(2) SVS_CASE(3) SVS_CASE(4) SVS_CASE(5) SVS_CASE(6) SVS_CASE(7) SVS_CASE(8)
-            default: return fail(SVS_ERR_INVALID_ARG, "internal: rows=%d", rows);
-        }
-#undef SVS_CASE
+        if (rows == 1)
+            hipLaunchKernelGGL((svs::embed_bgr_kernel<1, QM, false>), grid, dim3(SVS_WG), lds_pad, st, in, out, ref, g, c, qp, bits,
+                               bit_offset, n_bits, n_words);
+        else if (rows == 2)
+            hipLaunchKernelGGL((svs::embed_bgr_kernel<2, QM, false>), grid, dim3(SVS_WG), lds_pad, st, in, out, ref, g, c, qp, bits,
+                               bit_offset, n_bits, n_words);
+        else
+            return fail(SVS_ERR_INVALID_ARG, "internal: rows=%d", rows);
     }
     SVS_HIP(hipGetLastError());
     return SVS_OK;
@@ -463,17 +464,14 @@ int svs_embed_dev(const uint8_t *d_gray, uint8_t *d_stego, const svs_planes *pla
     const int qm = make_qim(use == 0 ? 1.0 : delta, &qp);
     if (flags & ~(SVS_EXACT_POCKETFFT | SVS_EXACT_GUARDED)) return fail(SVS_ERR_INVALID_ARG, "unknown flags 0x%x", flags);
     const int rows = rows_for(n);
-    // Which kernel family (include/svsdct.h `flags`).  The streaming kernel (embed_kernel: cheap arithmetic + in-kernel exact
-    // replay of the blocks it cannot decide) is bit-identical to the reference with one and two coefficient rows (n <= 15:
-    // rigorous guard) and serves BOTH flags there with the same launch; with three and more rows it is the FAST mode's
-    // kernel (per-pixel guard of 2^-13, contract-level) and GUARDED takes the lane-per-block pocketfft kernel.
-    // Outside the delta range the guard is useless (every block undecided below, BETA > 1/8 above): exact kernels.
+    // Which kernel family (include/svsdct.h `flags`).  Every mode produces the reference's stego pixels; the flags only choose
+    // between two ways of getting them.  The streaming kernel (embed_kernel: cheap arithmetic, rigorous guard, in-kernel exact
+    // replay of the blocks it cannot decide) covers one and two coefficient rows (n <= 15) inside the guard's delta range and
+    // serves flags 0 and SVS_EXACT_GUARDED alike; everything else - n >= 16, delta outside the range, SVS_EXACT_POCKETFFT -
+    // runs the lane-per-block pocketfft kernel.
     const bool in_range = delta >= SVS_GUARD_DELTA_MIN && delta <= SVS_GUARD_DELTA_MAX;
-    bool streaming = use > 0 && in_range && !(flags & SVS_EXACT_POCKETFFT) && (rows <= 2 || !(flags & SVS_EXACT_GUARDED));
+    bool streaming = use > 0 && in_range && !(flags & SVS_EXACT_POCKETFFT) && rows <= 2;
 #if defined(SVS_EXPERIMENTS)
-    // (the streaming kernel stays ahead of the lane-per-block pocketfft kernel up to all eight coefficient rows: 1.20 vs
-    // 1.33 ms per 200 x 4K frames at n = 63, profiles/r03_many_coefficients.txt; SVS_FAST_MAX_ROWS is the A/B knob)
-    if (rows > (int)knob("SVS_FAST_MAX_ROWS", 8)) streaming = false;
     if (knob("SVS_GUARDED_OFF", 0) != 0 || (rows == 2 && knob("SVS_GUARDED2_OFF", 0) != 0)) streaming = false;   // A/B: exact kernel
 #endif
     // SVS_EXACT_BPL=2 (experiment knob): exact arithmetic on two adjacent blocks per lane with every transform instruction
@@ -509,15 +507,13 @@ int svs_embed_dev(const uint8_t *d_gray, uint8_t *d_stego, const svs_planes *pla
     const uint64_t words = (last_byte + 3) / 4;
     if (words >= (1ull << 32)) return fail(SVS_ERR_INVALID_ARG, "payload too large for one call");
     const uint32_t *bw = reinterpret_cast<const uint32_t *>(d_bits_packed);
-    if (rows <= 2) {
-        svs::make_guard(delta, rows, &qp);
+    svs::make_guard(delta, rows, &qp);
 #if defined(SVS_EXPERIMENTS)
-        if (const char *sc = getenv("SVS_GUARD_SCALE")) {   // NOT bit-identical any more when < 1 (experiments library only)
-            const float f = (float)atof(sc);
-            qp.g_sum *= f; qp.g_resid *= f; qp.g_delta *= f;
-        }
-#endif
+    if (const char *sc = getenv("SVS_GUARD_SCALE")) {   // NOT bit-identical any more when < 1 (experiments library only)
+        const float f = (float)atof(sc);
+        qp.g_sum *= f; qp.g_resid *= f; qp.g_delta *= f;
     }
+#endif
     int rc;
 #define SVS_GO(QM)                                                                                                   \
     rc = two ? launch_embed<QM, 2>(rows, total, st, d_gray, d_stego, g, qp, bw, bit_offset, use, (uint32_t)words)    \
@@ -760,17 +756,16 @@ int svs_embed_bgr_dev(const uint8_t *d_bgr_in, int64_t in_row_pitch, int64_t in_
     if (!(delta > 0.0) || n == 0) use = 0;
     if (use > 0 && (!d_bits_packed || ((uintptr_t)d_bits_packed % 4)))
         return fail(SVS_ERR_INVALID_ARG, "bits pointer NULL or not 4-byte aligned");
-    // kernel family as in svs_embed_dev: the streaming arithmetic (with its in-kernel exact replay) - bit-identical with one
-    // and two coefficient rows, where both flags run it; FAST only with more rows; the exact arithmetic otherwise, and
-    // whenever a non-empty payload cannot be embedded (every block is then round-tripped, which only it reproduces)
+    // kernel family as in svs_embed_dev: the streaming arithmetic (with its in-kernel exact replay) for one and two coefficient
+    // rows inside the guard's delta range, whatever the flags; the exact arithmetic otherwise, and whenever a non-empty
+    // payload cannot be embedded (every block is then round-tripped, which only it reproduces)
     const int rows_n = rows_for(n);
     const bool in_range = delta >= SVS_GUARD_DELTA_MIN && delta <= SVS_GUARD_DELTA_MAX;
-    const bool streaming = use > 0 && in_range && !(flags & SVS_EXACT_POCKETFFT) && (rows_n <= 2 || !(flags & SVS_EXACT_GUARDED)) &&
-                           rows_n <= (int)knob("SVS_FAST_MAX_ROWS", 8);
+    const bool streaming = use > 0 && in_range && !(flags & SVS_EXACT_POCKETFFT) && rows_n <= 2;
     const bool exact = !streaming && (use > 0 || n_bits > 0);
     svs::QimParams qp;
     const int qm = make_qim(use == 0 ? 1.0 : delta, &qp);
-    if (streaming && rows_n <= 2) svs::make_guard(delta, rows_n, &qp);
+    if (streaming) svs::make_guard(delta, rows_n, &qp);
     g.xcd_chunk = knob("SVS_EMBED_XCD_CHUNK", kEighth);
     const hipStream_t st = (hipStream_t)stream;
     const uint32_t *bw = reinterpret_cast<const uint32_t *>(d_bits_packed);

@@ -472,11 +472,10 @@ __global__ __launch_bounds__(SVS_WG, SVS_EXACT2_MIN_WAVES) void embed_exact_pair
 // workgroups of SVS_WG.  BPL = 2 (16-byte row accesses) needs an even number of blocks per row and 16-byte aligned rows
 // (the host checks) and is instantiated for one coefficient row only.
 // HBM traffic per block: 64 B read + 64 B written + n payload bits read - nothing else, whatever the content.
-//   phase 1  lane = block: the cheap arithmetic (svs_block.hpp) - U <= 2 (n <= 15): embed_block_guarded / _guarded2
-//            (pocketfft-identical payload coefficients, sparse inverse, rigorous per-block error bound: the result is the
-//            reference's, bit for bit; FAST and GUARDED are the same launch); U >= 3 (FAST only): embed_block (FMA-factored
-//            transform, per-pixel guard of SVS_FAST_GUARD).  Either returns "undecided" for the blocks whose truncation
-//            the reference's own float32 noise decides.
+//   phase 1  lane = block: the cheap arithmetic (svs_block.hpp) - embed_block_guarded (n <= 7) / _guarded2 (n = 8..15):
+//            pocketfft-identical payload coefficients, sparse inverse, rigorous per-block error bound - the result is the
+//            reference's, bit for bit.  Returns "undecided" for the blocks whose truncation the reference's own float32
+//            noise decides.  (n >= 16 does not come here: every mode runs embed_exact_kernel.)
 //   phase 2  the wave's undecided blocks are compacted into a wave-private LDS worklist (ballot + mbcnt: no atomics, no
 //            barrier) and redone with the pocketfft-identical arithmetic by EIGHT LANES PER BLOCK: lane r of a group
 //            transforms column r, then row r, of its block - the four 1-D passes of the reference (vertical / horizontal
@@ -493,9 +492,6 @@ __global__ __launch_bounds__(SVS_WG, SVS_EXACT2_MIN_WAVES) void embed_exact_pair
 // ---------------------------------------------------------------------------------------
 #ifndef SVS_GUARD_CAP
 #define SVS_GUARD_CAP 32    // worklist entries per wave and round (80 B each) of the one-row (rigorous guard) embed kernel
-#endif
-#ifndef SVS_GUARD_CAP_FAST
-#define SVS_GUARD_CAP_FAST 8   // ... of the kernels with more rows, where undecided blocks are rare outside flat content
 #endif
 
 template <int QM>
@@ -555,19 +551,17 @@ __device__ __forceinline__ void guard_replay8(GuardEntry *e, float *t, uint32_t 
 
 // phase 1 for one block whose rows are ax/ay, in place: stego pixels out - unless the block is undecided, then its original
 // pixels are left untouched (svs_block.hpp decides before it writes).  -> undecided
-template <int U, int QM>
+template <int U, int QM, int NFIX = 0>
 __device__ __forceinline__ bool guard_phase1(uint32_t (&ax)[8], uint32_t (&ay)[8], uint32_t n, uint64_t first,
                                              const QimParams &qp, const uint32_t *__restrict__ bits,
                                              uint64_t bit_offset, uint64_t n_bits, uint32_t n_words,
                                              uint32_t *keep_hi = nullptr) {
-    uint32_t hi, lo = 0;
-    if constexpr (U <= 2) hi = window32(payload_qword(bits, n_words, bit_offset + first), (uint32_t)((bit_offset + first) & 31u));
-    else payload_window(bits, n_words, bit_offset + first, hi, lo);
+    const uint32_t hi = window32(payload_qword(bits, n_words, bit_offset + first), (uint32_t)((bit_offset + first) & 31u)), lo = 0;
     if (keep_hi) *keep_hi = hi;
     const uint32_t nb = block_budget(first, n_bits, n);
+    static_assert(U <= 2, "n <= 15: with more coefficient rows every mode runs the lane-per-block pocketfft kernel");
     if constexpr (U == 1) return embed_block_guarded<QM>(ax, ay, n, nb, hi, lo, qp);          // n <= 7: rigorous, 8 tests
-    else if constexpr (U == 2) return embed_block_guarded2<QM>(ax, ay, n, nb, hi, lo, qp);    // n = 8..15: rigorous, 64 tests
-    else return embed_block<U, QM>(ax, ay, n, nb, hi, lo, qp);                                // n >= 16: FAST only
+    else return embed_block_guarded2<QM, NFIX>(ax, ay, n, nb, hi, lo, qp);                    // n = 8..15: rigorous, 64 tests
 }
 // the same with the window handed in (two blocks per lane: both windows come from one payload_qword)
 template <int U, int QM>
@@ -695,10 +689,9 @@ __device__ __forceinline__ uint32_t guard_phase2_wg(GuardEntry *entries, float *
     return total;
 }
 
-// Register targets (waves per SIMD) of the embed kernels: natural allocation everywhere but at four coefficient rows.
-// (Round 3 allocated the two-row FAST kernel for its hot path - 72 VGPRs, 7 waves - because its replay was rare; that kernel
-// is gone: with two rows FAST and GUARDED run the rigorous arithmetic, whose replay runs in every workgroup.  Three rows
-// forced to 6 waves spilled 116 B: 1.11 vs 0.79 ms at n = 20.  One row: spills in the replay cost 1.90 vs 1.71 ms.)
+// Register targets (waves per SIMD) of the embed kernels: natural allocation.  (One row: 96 VGPRs, 5 waves; spills in the
+// replay cost 1.90 vs 1.71 ms.  Two rows: 103 VGPRs, 4 waves; a target of 5 waves spills 68 B and costs 3.26 vs 2.74 ms
+// per 600 x 4K, 6 waves 4.30 ms - profiles/r04_ab_two_row.txt.)
 #ifndef SVS_KEEP_WINDOW
 #define SVS_KEEP_WINDOW 1
 #endif
@@ -712,16 +705,18 @@ __device__ __forceinline__ uint32_t guard_phase2_wg(GuardEntry *entries, float *
 #define SVS_U2_MIN_WAVES 1   // natural allocation (about 100 VGPRs, 4 waves per SIMD)
 #endif
 template <int U>
-constexpr int kEmbedMinWaves = U == 4 ? 4 : (U == 2 ? SVS_U2_MIN_WAVES : 1);
-template <int U, int QM, int BPL>
+constexpr int kEmbedMinWaves = U == 2 ? SVS_U2_MIN_WAVES : 1;
+template <int U, int QM, int BPL, int NFIX = 0>   // NFIX: compile-time n (two rows only; svs_capi.hip instantiates the GUI's default 10)
 __global__ __launch_bounds__(SVS_WG, kEmbedMinWaves<U>) void embed_kernel(const uint8_t *gray,
                                                     uint8_t *stego, const Geometry g, const QimParams qp,
                                                     const uint32_t *__restrict__ bits, const uint64_t bit_offset,
                                                     const uint64_t n_bits, const uint32_t n_words,
                                                     unsigned long long *__restrict__ replay_counter) {
+    static_assert(U <= 2, "n <= 15 (svs_capi.hip: more coefficient rows run embed_exact_kernel in every mode)");
     static_assert(BPL == 1 || U == 1, "two blocks per lane is instantiated for one coefficient row only");
+    static_assert(NFIX == 0 || U == 2, "compile-time n: two coefficient rows only");
     constexpr bool WGPOOL = U == 2 && SVS_U2_WGPOOL;
-    constexpr int CAP = WGPOOL ? SVS_GUARD_CAP_WG : (U <= 2 ? SVS_GUARD_CAP : SVS_GUARD_CAP_FAST);
+    constexpr int CAP = WGPOOL ? SVS_GUARD_CAP_WG : SVS_GUARD_CAP;
     __shared__ GuardEntry entries[WGPOOL ? 1 : SVS_WG / 64][CAP];
     __shared__ float tiles[SVS_WG / 64][8 * SVS_GUARD_TILE];
     __shared__ uint32_t wg_undecided;
@@ -736,7 +731,7 @@ __global__ __launch_bounds__(SVS_WG, kEmbedMinWaves<U>) void embed_kernel(const 
     // n <= 15: the payload window of a block is its first word - kept in a register from phase 1, because re-reading it for
     // the worklist is a global load in the life of every wave that replays (one-row kernel: 1.58 instead of 1.73 ms per
     // 600 x 4K, and 93 instead of 100 VGPRs)
-    constexpr bool KEPT = U <= 2 && SVS_KEEP_WINDOW;
+    constexpr bool KEPT = SVS_KEEP_WINDOW;
     uint32_t hi_a = 0, hi_b = 0;
     typename RowVec<BPL>::type v[8];
     uint32_t ax[8], ay[8], bx[8], by[8];
@@ -763,7 +758,7 @@ __global__ __launch_bounds__(SVS_WG, kEmbedMinWaves<U>) void embed_kernel(const 
                 if (first + n < n_bits)   // a budget of 0 (only the lane the payload ends in can see it) leaves block B as it is
                     und_b = guard_phase1_window<U, QM>(bx, by, n, first + n, qp, n_bits, hi_b);
             } else {
-                und_a = guard_phase1<U, QM>(ax, ay, n, first, qp, bits, bit_offset, n_bits, n_words, KEPT ? &hi_a : nullptr);
+                und_a = guard_phase1<U, QM, NFIX>(ax, ay, n, first, qp, bits, bit_offset, n_bits, n_words, KEPT ? &hi_a : nullptr);
             }
         }
     }

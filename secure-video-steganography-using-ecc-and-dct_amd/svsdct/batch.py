@@ -22,18 +22,17 @@ from .native import Planes
 
 MAX_AC = 63
 
-# Transform mode (include/svsdct.h `flags`):
-#   "guarded" stego pixels bit-identical to the reference.  n_ac <= 15: the streaming kernel (cheap sparse transform wherever a
-#            rigorous bound on the reference's float32 round-trip noise proves it equals the reference's truncation, the
-#            pocketfft-identical arithmetic inside the same launch for the few blocks where it cannot; 8 tests per block
-#            at n_ac <= 7, 64 at n_ac = 8..15); n_ac >= 16 or delta outside [0.25, 4096]: the "exact" kernels.  Extraction:
-#            the "fast" kernels (their bits are the reference's for any input).
-#            Default of the NumPy level, the drop-in operator and the video pipelines.
-#   "fast"   n_ac <= 7: the same launch as "guarded".  n_ac >= 8: FMA-factored DCT on the coefficient rows the payload
-#            touches with a per-pixel guard - contract parity (bits exact, PSNR within 0.01 dB).  Default of the
-#            device-pointer (throughput) level.
+# Transform mode (include/svsdct.h `flags`).  Every mode produces the reference's stego pixels and bits (round 4); the modes
+# only differ in which kernels get there:
+#   "guarded" n_ac <= 15 and 0.25 <= delta <= 4096: the streaming kernel (cheap sparse transform wherever a rigorous bound
+#            on the reference's float32 round-trip noise proves it equals the reference's truncation, the pocketfft-identical
+#            arithmetic inside the same launch for the blocks where it cannot; 8 tests per block at n_ac <= 7, 64 at
+#            n_ac = 8..15); otherwise the "exact" kernels.  Extraction: n_ac <= 7 the pocketfft-identical forward, n_ac >= 8 the
+#            FMA-factored forward with a proven per-block tie margin (the reference's bits for any input).  The default.
+#   "fast"   flags = 0 of the C ABI: the same launches as "guarded" (rounds 1-3 had a separate contract-level embed
+#            arithmetic for n_ac >= 8 here; it is gone, see csrc/svs_block.hpp).
 #   "exact"  pocketfft-identical arithmetic on every block, one lane per block - the yardstick (VALU-bound).
-# SVS_DCT_MODE=fast|exact|guarded overrides both defaults.
+# SVS_DCT_MODE=fast|exact|guarded overrides the defaults.
 _ENV_MODE = os.environ.get("SVS_DCT_MODE")
 
 

@@ -31,26 +31,6 @@ struct Blk {
     }
 };
 
-template <int U>
-bool embed_u(Blk &raw, uint32_t n, uint32_t nb, uint32_t hi, uint32_t lo, const svs::QimParams &qp, int qm) {
-    if (qm == svs::QM_DOUBLE) return svs::embed_block<U, svs::QM_DOUBLE>(raw.x, raw.y, n, nb, hi, lo, qp);
-    if (qm == svs::QM_POW2) return svs::embed_block<U, svs::QM_POW2>(raw.x, raw.y, n, nb, hi, lo, qp);
-    return svs::embed_block<U, svs::QM_F32>(raw.x, raw.y, n, nb, hi, lo, qp);
-}
-
-// -> true: the block is to be replayed with the exact arithmetic (svs::embed_block's return value); three and more rows only
-bool embed_dispatch(int rows, Blk &raw, uint32_t n, uint32_t nb, uint32_t hi, uint32_t lo,
-                    const svs::QimParams &qp, int dbl) {
-    switch (rows) {
-        case 3: return embed_u<3>(raw, n, nb, hi, lo, qp, dbl);
-        case 4: return embed_u<4>(raw, n, nb, hi, lo, qp, dbl);
-        case 5: return embed_u<5>(raw, n, nb, hi, lo, qp, dbl);
-        case 6: return embed_u<6>(raw, n, nb, hi, lo, qp, dbl);
-        case 7: return embed_u<7>(raw, n, nb, hi, lo, qp, dbl);
-        default: return embed_u<8>(raw, n, nb, hi, lo, qp, dbl);
-    }
-}
-
 // two adjacent blocks through the packed pair form (what embed_exact_pair_kernel runs)
 void embed_exact_pair_dispatch(Blk &a, Blk &b, uint32_t n, uint32_t nb_a, uint32_t nb_b, uint32_t hi_a, uint32_t lo_a,
                                uint32_t hi_b, uint32_t lo_b, const svs::QimParams &qp, int qm) {
@@ -123,15 +103,13 @@ uint64_t emu_embed(const uint8_t *gray, uint8_t *stego, int F, int H, int W, dou
     if (!(delta > 0.0) || n == 0) use = 0;
     svs::QimParams qp;
     const int dbl = make_qim(use ? delta : 1.0, &qp);
-    // exact == 4: GUARDED - the cheap path wherever its rigorous error bound decides every pixel, the exact arithmetic
-    // elsewhere (same routing as svs_embed_dev: one or two coefficient rows, delta inside the guard's range; anything else is
-    // plain EXACT).  FAST (exact == 0) takes the same path for one and two rows; with more rows it runs the FMA-factored
-    // arithmetic with its per-pixel guard of 2^-13.  Outside the delta range both modes run the exact arithmetic.
+    // exact == 0 (flags 0) and exact == 4 (SVS_EXACT_GUARDED): the cheap path wherever its rigorous error bound decides every
+    // pixel, the exact arithmetic elsewhere (same routing as svs_embed_dev: one or two coefficient rows, delta inside the
+    // guard's range; anything else is plain EXACT).  Every mode gives the reference's pixels.
     const bool in_range = delta >= SVS_GUARD_DELTA_MIN && delta <= SVS_GUARD_DELTA_MAX;
     const bool guarded = use > 0 && in_range && (exact == 4 || exact == 0) && svs::rows_for(n) <= 2;
     if (guarded) svs::make_guard(delta, svs::rows_for(n), &qp);
-    if (exact == 4 && !guarded) exact = 1;
-    if (exact == 0 && !in_range) exact = 1;   // svs_embed_dev: out-of-range delta
+    if ((exact == 4 || exact == 0) && !guarded) exact = 1;
     if (use == 0) {
         if (n_bits > 0) {  // nothing consumed -> every block entered and round-tripped (either mode: svs_embed_dev)
             for (uint64_t gb = 0; gb < total; ++gb) {
@@ -172,14 +150,6 @@ uint64_t emu_embed(const uint8_t *gray, uint8_t *stego, int F, int H, int W, dou
         }
         if (guarded) {
             if (embed_guarded_dispatch(raw, (uint32_t)n, nb, hi, lo, qp, dbl)) {
-                raw.load(p, (size_t)W);
-                embed_exact_dispatch(raw, (uint32_t)n, nb, hi, lo, qp, dbl);
-                if (n_replayed) ++*n_replayed;
-            }
-        } else if (!exact) {
-            // FAST, three and more coefficient rows: blocks with a pixel whose predicted value lies within 2^-13 of the
-            // integer grid are replayed with the exact arithmetic (inside the same launch on the device, svs_device.hpp)
-            if (embed_dispatch(svs::rows_for(n), raw, (uint32_t)n, nb, hi, lo, qp, dbl)) {
                 raw.load(p, (size_t)W);
                 embed_exact_dispatch(raw, (uint32_t)n, nb, hi, lo, qp, dbl);
                 if (n_replayed) ++*n_replayed;

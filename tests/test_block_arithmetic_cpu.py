@@ -83,9 +83,11 @@ def test_golden_vectors(golden):
 
 @pytest.mark.parametrize("n_ac,delta", CONTRACT_POINTS)
 def test_fast_mode_psnr_contract_on_structured_content(n_ac, delta):
-    """FAST mode against the oracle on content full of flat / one-dimensional blocks: stego PSNR within 0.01 dB (blocks
-    whose change is structurally zero are replayed with the exact arithmetic), the reference's receiver reads the same
-    bits from either stego frame, and FAST extraction of either frame equals the oracle's - no masks."""
+    """flags = 0 ("fast") against the oracle on content full of flat / one-dimensional / smooth blocks, under random, all-zero
+    and sparse payloads: since round 4 every embed mode is BIT-IDENTICAL to the reference (n <= 15: the rigorous guard with
+    its in-kernel exact replay; n >= 16: the pocketfft-identical arithmetic) - which is more than north_star's contract
+    (stego PSNR within 0.01 dB, extracted bits exact), asserted as well.  FAST extraction of stego, reference stego and
+    never-embedded cover equals the oracle's - no masks."""
     h, w = 256, 384
     for name, cover in structured_covers(h, w).items():
         cap = batch.capacity_bits(1, h, w, n_ac)
@@ -94,15 +96,12 @@ def test_fast_mode_psnr_contract_on_structured_content(n_ac, delta):
             stego, used = emu_embed(cover, delta, n_ac, payload, replayed=replayed)
             _, ref, ref_used = orc.frame_embed(cover, delta, payload, n_ac)
             assert used == ref_used == cap
+            assert np.array_equal(stego[0], ref), (name, pname)
             a, b = orc.psnr_u8(cover, stego[0]), orc.psnr_u8(cover, ref)
             assert psnr_gap(a, b) <= PSNR_TOL_DB, (name, pname, a, b)
-            if pname == "bernoulli_half" and (name in ("flat_128", "half_letterbox", "checker_8") or
-                                              (name == "constant_rows" and n_ac <= 7)):
-                assert replayed[0] > 0, name                 # the slow path is really exercised
-            # delta >= 8 is error-free unless a pixel clips (large steps do clip: 1.5 * 64 per coefficient):
-            # wherever the reference's own round trip returns the payload, so does this one
-            if delta >= 8 and np.array_equal(orc.frame_extract_bits(ref, delta, n_ac), payload):
-                assert np.array_equal(orc.frame_extract_bits(stego[0], delta, n_ac), payload), (name, pname)
+            if n_ac <= 15 and pname == "bernoulli_half" and (name in ("flat_128", "half_letterbox", "checker_8") or
+                                                             (name == "constant_rows" and n_ac <= 7)):
+                assert replayed[0] > 0, name                 # the exact replay is really exercised
             for src in (stego[0], ref, cover) if pname == "bernoulli_half" else (stego[0],):
                 assert np.array_equal(emu_extract(src, delta, n_ac), orc.frame_extract_bits(src, delta, n_ac)), (name, pname)
 
@@ -110,8 +109,8 @@ def test_fast_mode_psnr_contract_on_structured_content(n_ac, delta):
 @pytest.mark.parametrize("n_ac,delta", [(8, 20), (10, 20), (10, 32), (10, 64), (11, 64), (15, 100), (16, 64), (63, 64)])
 def test_fast_mode_on_smooth_content_with_zero_heavy_payloads(n_ac, delta):
     """VERDICT r03 weak #1, at the size of the review's probe (544 x 960): smooth ramps / sinusoid / sigma-1 Gaussian /
-    near-black under all-zero and 1 %-ones payloads.  Before the q' != 0 condition of embed_block's level 1 the horizontal
-    ramp was +0.59 dB off the oracle with no block replayed."""
+    near-black under all-zero and 1 %-ones payloads.  Round 3's FAST arithmetic put the horizontal ramp +0.59 dB off the
+    oracle with no block replayed; flags = 0 now runs the bit-identical kernels."""
     h, w = 544, 960
     covers = structured_covers(h, w)
     for name in SMOOTH_COVERS:
@@ -122,7 +121,7 @@ def test_fast_mode_on_smooth_content_with_zero_heavy_payloads(n_ac, delta):
             _, ref, ref_used = orc.frame_embed(cover, delta, payload, n_ac)
             assert used == ref_used == cap
             a, b = orc.psnr_u8(cover, stego[0]), orc.psnr_u8(cover, ref)
-            assert psnr_gap(a, b) <= PSNR_TOL_DB, (name, pname, a, b)
+            assert psnr_gap(a, b) <= PSNR_TOL_DB and np.array_equal(stego[0], ref), (name, pname, a, b)
             assert np.array_equal(emu_extract(stego[0], delta, n_ac), orc.frame_extract_bits(stego[0], delta, n_ac)), (name, pname)
 
 
