@@ -1078,7 +1078,10 @@ SVS_HD float qim_change(float c, uint32_t bit, const QimParams &qp) {
 
 // NFIX (8..15, or 0 = run-time n): the coefficient count at compile time - the quantiser loop loses its wave-uniform tests,
 // outputs of the row-1 transform that nobody reads and inverse inputs that are known zeros disappear from the code.
-template <int QM, int NFIX = 0>
+// INPLACE: the stego bytes replace the pixels of rx / ry as they are computed (each column touches only its own byte of the
+// row dwords) and an UNDECIDED block is left half-written - for a caller that has parked the original rows elsewhere (the
+// two-row kernel parks them in LDS, where the exact replay wants them anyway: 16 registers and 16 moves less).
+template <int QM, int NFIX = 0, bool INPLACE = false>
 SVS_HD bool embed_block_guarded2(uint32_t (&rx)[8], uint32_t (&ry)[8], uint32_t n_rt, uint32_t nb, uint32_t hi, uint32_t lo,
                                  const QimParams &qp) {
     static_assert(NFIX == 0 || (NFIX >= 8 && NFIX <= 15), "two coefficient rows");
@@ -1135,7 +1138,9 @@ SVS_HD bool embed_block_guarded2(uint32_t (&rx)[8], uint32_t (&ry)[8], uint32_t 
     constexpr float kHalf = 0.5f - 0x1p-16f;
     constexpr float kMid = 0.5f + 0x1p-16f;
     float near_cc = 1.0f, near_ce = 1.0f, near_ee = 1.0f;   // smallest distance from the grid per position class
-    uint32_t nx[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ny[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // the stego rows, committed only if decided
+    uint32_t sx[8] = {0, 0, 0, 0, 0, 0, 0, 0}, sy[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // !INPLACE: the stego rows, committed only if decided
+    uint32_t (&nx)[8] = INPLACE ? rx : sx;
+    uint32_t (&ny)[8] = INPLACE ? ry : sy;
     const float ck[4] = {SVS_C1, SVS_C3, SVS_C5, SVS_C7};
     // CLS_C: class of this column's pixels in rows 0, 3, 4, 7;  CLS_E: in rows 1, 2, 5, 6
 #define SVS_PREDCOL(X, W, NW, B, CLS_C, CLS_E)                                                  \
@@ -1154,10 +1159,12 @@ SVS_HD bool embed_block_guarded2(uint32_t (&rx)[8], uint32_t (&ry)[8], uint32_t 
     SVS_PREDCOL(6, ry, ny, 2, near_ce, near_ee) SVS_PREDCOL(7, ry, ny, 3, near_cc, near_ce)
 #undef SVS_PREDCOL
     const bool undecided = nb > 0 && !(near_cc >= beta_cc && near_ce >= beta_ce && near_ee >= beta_ee);
-    if (undecided) return true;   // the block keeps its original pixels
+    if constexpr (!INPLACE) {
+        if (undecided) return true;   // the block keeps its original pixels
 #pragma unroll
-    for (int r = 0; r < 8; ++r) { rx[r] = nx[r]; ry[r] = ny[r]; }
-    return false;
+        for (int r = 0; r < 8; ++r) { rx[r] = nx[r]; ry[r] = ny[r]; }
+    }
+    return undecided;
 }
 
 // BETA's coefficients for `rows` coefficient rows (1 or 2), rounded up; host side

@@ -130,9 +130,12 @@ struct Tuning {
     uint32_t chunk;
 };
 
+#ifndef SVS_U2_BPL
+#define SVS_U2_BPL 1   // blocks per lane of the two-row embed kernel (build knob for the A/B)
+#endif
 Tuning embed_tuning(int rows, const svs_planes *p, const void *a, const void *b) {
-    Tuning t{rows == 1, kEighth};
-    t.two_blocks = rows == 1 && knob("SVS_EMBED_BPL", t.two_blocks ? 2 : 1) == 2;
+    Tuning t{rows == 1 || (rows == 2 && SVS_U2_BPL == 2), kEighth};
+    t.two_blocks = (rows == 1 || (rows == 2 && SVS_U2_BPL == 2)) && knob("SVS_EMBED_BPL", t.two_blocks ? 2 : 1) == 2;
     t.chunk = knob("SVS_EMBED_XCD_CHUNK", t.chunk);
     t.two_blocks = t.two_blocks && rows_allow_two_blocks(p, a, b);
     return t;
@@ -177,10 +180,22 @@ int launch_embed(int rows, uint64_t total, hipStream_t st, const uint8_t *gray, 
             return SVS_OK;
         }
     }
-    if (rows < 1 || rows > 2 || (BPL == 2 && rows != 1)) return fail(SVS_ERR_INVALID_ARG, "internal: rows=%d, %d blocks per lane", rows, BPL);
-    if constexpr (BPL == 2) {   // two blocks per lane is only instantiated (and only pays) for one coefficient row
-        hipLaunchKernelGGL((svs::embed_kernel<1, QM, 2>), grid, dim3(SVS_WG), lds_pad, st, gray, stego, g, qp, bits, bit_offset, n_bits,
-                           n_words, g_guard_counter);
+    if (rows < 1 || rows > 2) return fail(SVS_ERR_INVALID_ARG, "internal: rows=%d, %d blocks per lane", rows, BPL);
+    if constexpr (BPL == 2) {
+        if (rows == 1)
+            hipLaunchKernelGGL((svs::embed_kernel<1, QM, 2>), grid, dim3(SVS_WG), lds_pad, st, gray, stego, g, qp, bits, bit_offset, n_bits,
+                               n_words, g_guard_counter);
+#if SVS_U2_BPL == 2   // A/B build only: two adjacent blocks per lane with a joint replay need 150 VGPRs (3 waves per SIMD) and end
+                      // level with one block per lane (2.57 vs 2.57 ms per 600 x 4K, profiles/r04_ab_two_row.txt)
+        else if (g.n_ac == 10)
+            hipLaunchKernelGGL((svs::embed_kernel<2, QM, 2, 10>), grid, dim3(SVS_WG), lds_pad, st, gray, stego, g, qp, bits, bit_offset, n_bits,
+                               n_words, g_guard_counter);
+        else
+            hipLaunchKernelGGL((svs::embed_kernel<2, QM, 2>), grid, dim3(SVS_WG), lds_pad, st, gray, stego, g, qp, bits, bit_offset, n_bits,
+                               n_words, g_guard_counter);
+#else
+        else return fail(SVS_ERR_INVALID_ARG, "internal: rows=%d with two blocks per lane", rows);
+#endif
     } else if (rows == 1) {
         hipLaunchKernelGGL((svs::embed_kernel<1, QM, 1>), grid, dim3(SVS_WG), lds_pad, st, gray, stego, g, qp, bits, bit_offset, n_bits,
                            n_words, g_guard_counter);

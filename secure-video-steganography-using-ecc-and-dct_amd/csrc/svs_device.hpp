@@ -494,14 +494,16 @@ __global__ __launch_bounds__(SVS_WG, SVS_EXACT2_MIN_WAVES) void embed_exact_pair
 #define SVS_GUARD_CAP 32    // worklist entries per wave and round (80 B each) of the one-row (rigorous guard) embed kernel
 #endif
 
+// px: the block's 16 row dwords (low, high per row) in LDS - original pixels in, exact stego pixels out
 template <int QM>
-__device__ __forceinline__ void guard_replay8(GuardEntry *e, float *t, uint32_t r, uint32_t n, const QimParams &qp) {
+__device__ __forceinline__ void guard_replay8(uint32_t *px, uint32_t hi, uint32_t lo, uint32_t nb, float *t, uint32_t r, uint32_t n,
+                                              const QimParams &qp) {
     float a[8], b[8];
     // vertical forward transform of pixel column r
     {
         const uint32_t sh = 8u * (r & 3u), half = r >> 2;
 #pragma unroll
-        for (int y = 0; y < 8; ++y) a[y] = (float)((e->px[2 * y + half] >> sh) & 0xffu);
+        for (int y = 0; y < 8; ++y) a[y] = (float)((px[2 * y + half] >> sh) & 0xffu);
     }
     pf::dct2_8(a, b);                       // b[u] = V[u][r]
 #pragma unroll
@@ -520,7 +522,6 @@ __device__ __forceinline__ void guard_replay8(GuardEntry *e, float *t, uint32_t 
     wave_lds_fence();
     // QIM on flat indices k = 8 u + r in 1..n (config_and_setup.py:139-158): one coefficient per lane and row, so a wave
     // runs n / 8 + 1 quantiser sequences, each on all the lanes that have a coefficient
-    const uint32_t hi = e->hi, lo = e->lo, nb = e->nb;
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
         const uint32_t k = 8u * u + r;
@@ -545,8 +546,8 @@ __device__ __forceinline__ void guard_replay8(GuardEntry *e, float *t, uint32_t 
     pf::dct3_8(a, b);                       // pixel row r
     uint32_t lo4, hi4;
     store_row_trunc(b[0], b[1], b[2], b[3], b[4], b[5], b[6], b[7], lo4, hi4);   // np.uint8(np.clip(.)) (:171)
-    e->px[2 * r] = lo4;
-    e->px[2 * r + 1] = hi4;
+    px[2 * r] = lo4;
+    px[2 * r + 1] = hi4;
 }
 
 // phase 1 for one block whose rows are ax/ay, in place: stego pixels out - unless the block is undecided, then its original
@@ -564,13 +565,13 @@ __device__ __forceinline__ bool guard_phase1(uint32_t (&ax)[8], uint32_t (&ay)[8
     else return embed_block_guarded2<QM, NFIX>(ax, ay, n, nb, hi, lo, qp);                    // n = 8..15: rigorous, 64 tests
 }
 // the same with the window handed in (two blocks per lane: both windows come from one payload_qword)
-template <int U, int QM>
+template <int U, int QM, int NFIX = 0>
 __device__ __forceinline__ bool guard_phase1_window(uint32_t (&ax)[8], uint32_t (&ay)[8], uint32_t n, uint64_t first,
                                                     const QimParams &qp, uint64_t n_bits, uint32_t hi) {
     static_assert(U <= 2, "n <= 15");
     const uint32_t nb = block_budget(first, n_bits, n);
     if constexpr (U == 1) return embed_block_guarded<QM>(ax, ay, n, nb, hi, 0u, qp);
-    else return embed_block_guarded2<QM>(ax, ay, n, nb, hi, 0u, qp);
+    else return embed_block_guarded2<QM, NFIX>(ax, ay, n, nb, hi, 0u, qp);
 }
 
 // what phase 2 needs to rebuild a block's payload window (kept out of the lanes' registers on the common path)
@@ -621,7 +622,10 @@ __device__ __forceinline__ uint32_t guard_phase2(GuardEntry *entries, float *til
         const uint32_t todo = min(total - base, (uint32_t)CAP);
         for (uint32_t first = 0; first < todo; first += 8u) {
             const uint32_t idx = first + (lane >> 3);
-            if (idx < todo) guard_replay8<QM>(&entries[idx], tile + (lane >> 3) * SVS_GUARD_TILE, lane & 7u, n, qp);
+            if (idx < todo) {
+                GuardEntry *e = &entries[idx];
+                guard_replay8<QM>(e->px, e->hi, e->lo, e->nb, tile + (lane >> 3) * SVS_GUARD_TILE, lane & 7u, n, qp);
+            }
         }
         wave_lds_fence();
         if (mine_a) {
@@ -635,6 +639,40 @@ __device__ __forceinline__ uint32_t guard_phase2(GuardEntry *entries, float *til
             for (int r = 0; r < 8; ++r) { bx[r] = e->px[2 * r]; by[r] = e->px[2 * r + 1]; }
         }
         wave_lds_fence();   // the next round overwrites the entries
+    }
+    return total;
+}
+
+// phase 2 over PARKED rows (round 4; the two-row kernel): every lane has written its block's original rows to its slot of a
+// wave-private LDS array before phase 1 (slot = lane, SVS_SLOT_DWORDS apart), so phase 1 works in place and an undecided block
+// needs no deposit: the worklist is a list of {slot, budget, payload window} words, the exact replay reads and writes the
+// slots, and the owners of undecided blocks read theirs back.  No rounds: the worklist holds all 64 lanes if it must.
+#define SVS_SLOT_DWORDS 18   // 16 row dwords + 2: 8-byte aligned, and 16 consecutive lanes hit 16 different even banks
+template <int QM>
+__device__ __forceinline__ uint32_t guard_phase2_slots(uint32_t *slots, u32x2 *meta, float *tile, uint32_t lane, uint32_t n,
+                                                       const QimParams &qp, bool und, uint32_t nb, uint32_t hi,
+                                                       uint32_t (&ax)[8], uint32_t (&ay)[8]) {
+    const uint64_t mask = __ballot(und);
+    if (mask == 0) return 0;   // wave-uniform
+    const uint32_t total = (uint32_t)__popcll(mask);
+    if (und) {
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+        u32x2 m; m.x = lane | (nb << 8); m.y = hi;
+        meta[rank] = m;
+    }
+    wave_lds_fence();
+    for (uint32_t at = 0; at < total; at += 8u) {   // wave-uniform
+        const uint32_t idx = at + (lane >> 3);
+        if (idx < total) {
+            const u32x2 m = meta[idx];
+            guard_replay8<QM>(slots + (m.x & 0xffu) * SVS_SLOT_DWORDS, m.y, 0u, m.x >> 8, tile + (lane >> 3) * SVS_GUARD_TILE, lane & 7u, n, qp);
+        }
+    }
+    wave_lds_fence();
+    if (und) {
+        const u32x2 *mine = reinterpret_cast<const u32x2 *>(slots + lane * SVS_SLOT_DWORDS);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) { const u32x2 v = mine[r]; ax[r] = v.x; ay[r] = v.y; }
     }
     return total;
 }
@@ -676,7 +714,10 @@ __device__ __forceinline__ uint32_t guard_phase2_wg(GuardEntry *entries, float *
         const uint32_t todo = min(total - round0, (uint32_t)CAPWG);
         for (uint32_t at = 8u * wave; at < todo; at += 8u * (SVS_WG / 64)) {   // this wave's passes
             const uint32_t idx = at + (lane >> 3);
-            if (idx < todo) guard_replay8<QM>(&entries[idx], tile + (lane >> 3) * SVS_GUARD_TILE, lane & 7u, n, qp);
+            if (idx < todo) {
+                GuardEntry *e = &entries[idx];
+                guard_replay8<QM>(e->px, e->hi, e->lo, e->nb, tile + (lane >> 3) * SVS_GUARD_TILE, lane & 7u, n, qp);
+            }
         }
         __syncthreads();
         if (mine) {
@@ -706,6 +747,15 @@ __device__ __forceinline__ uint32_t guard_phase2_wg(GuardEntry *entries, float *
 #endif
 template <int U>
 constexpr int kEmbedMinWaves = U == 2 ? SVS_U2_MIN_WAVES : 1;
+// two rows, one block per lane: original rows parked in LDS and phase 1 in place (guard_phase2_slots: 68 instead of 103
+// VGPRs, 5 instead of 4 waves per SIMD, 29.7 KB of LDS per workgroup).  The kernel is bound by vector issue either way, and
+// which form the compiler schedules better depends on the quantiser: general delta (QM_F32, the GUI's default 20) 2.62 vs
+// 2.78 ms per 600 x 4K at n = 10 and 2.82 vs 2.93 at n = 15 in favour of the parked form, power-of-two delta 2.74 vs 2.65
+// against it - both orders of a 15-round A/B (profiles/r04_ab_two_row.txt).  1 = parked except for power-of-two delta,
+// 2 = always, 0 = never.
+#ifndef SVS_U2_INPLACE
+#define SVS_U2_INPLACE 1
+#endif
 template <int U, int QM, int BPL, int NFIX = 0>   // NFIX: compile-time n (two rows only; svs_capi.hip instantiates the GUI's default 10)
 __global__ __launch_bounds__(SVS_WG, kEmbedMinWaves<U>) void embed_kernel(const uint8_t *gray,
                                                     uint8_t *stego, const Geometry g, const QimParams qp,
@@ -713,11 +763,14 @@ __global__ __launch_bounds__(SVS_WG, kEmbedMinWaves<U>) void embed_kernel(const 
                                                     const uint64_t n_bits, const uint32_t n_words,
                                                     unsigned long long *__restrict__ replay_counter) {
     static_assert(U <= 2, "n <= 15 (svs_capi.hip: more coefficient rows run embed_exact_kernel in every mode)");
-    static_assert(BPL == 1 || U == 1, "two blocks per lane is instantiated for one coefficient row only");
     static_assert(NFIX == 0 || U == 2, "compile-time n: two coefficient rows only");
-    constexpr bool WGPOOL = U == 2 && SVS_U2_WGPOOL;
+    constexpr bool WGPOOL = U == 2 && BPL == 1 && SVS_U2_WGPOOL;
+    constexpr bool PARKED = U == 2 && BPL == 1 && !WGPOOL && (SVS_U2_INPLACE == 2 || (SVS_U2_INPLACE == 1 && QM != QM_POW2));
     constexpr int CAP = WGPOOL ? SVS_GUARD_CAP_WG : SVS_GUARD_CAP;
-    __shared__ GuardEntry entries[WGPOOL ? 1 : SVS_WG / 64][CAP];
+    // PARKED: per wave 64 slots of original rows + the worklist words; otherwise the worklist entries carry the rows
+    __shared__ __attribute__((aligned(16))) uint32_t park[PARKED ? SVS_WG / 64 : 1][PARKED ? 64 * SVS_SLOT_DWORDS : 2];
+    __shared__ u32x2 meta[PARKED ? SVS_WG / 64 : 1][PARKED ? 64 : 1];
+    __shared__ GuardEntry entries[PARKED ? 1 : (WGPOOL ? 1 : SVS_WG / 64)][PARKED ? 1 : CAP];
     __shared__ float tiles[SVS_WG / 64][8 * SVS_GUARD_TILE];
     __shared__ uint32_t wg_undecided;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -732,7 +785,7 @@ __global__ __launch_bounds__(SVS_WG, kEmbedMinWaves<U>) void embed_kernel(const 
     // the worklist is a global load in the life of every wave that replays (one-row kernel: 1.58 instead of 1.73 ms per
     // 600 x 4K, and 93 instead of 100 VGPRs)
     constexpr bool KEPT = SVS_KEEP_WINDOW;
-    uint32_t hi_a = 0, hi_b = 0;
+    uint32_t hi_a = 0, hi_b = 0, nb_a = 0;
     typename RowVec<BPL>::type v[8];
     uint32_t ax[8], ay[8], bx[8], by[8];
     int64_t off = 0;
@@ -754,9 +807,18 @@ __global__ __launch_bounds__(SVS_WG, kEmbedMinWaves<U>) void embed_kernel(const 
                 const uint32_t sh = (uint32_t)((bit_offset + first) & 31u);
                 hi_a = window32(q, sh);
                 hi_b = window32(q, sh + n);
-                und_a = guard_phase1_window<U, QM>(ax, ay, n, first, qp, n_bits, hi_a);
+                und_a = guard_phase1_window<U, QM, NFIX>(ax, ay, n, first, qp, n_bits, hi_a);
+                if constexpr (U == 2) SVS_SCHED_FENCE();   // one block at a time: interleaved, the two working sets need 150 VGPRs
                 if (first + n < n_bits)   // a budget of 0 (only the lane the payload ends in can see it) leaves block B as it is
-                    und_b = guard_phase1_window<U, QM>(bx, by, n, first + n, qp, n_bits, hi_b);
+                    und_b = guard_phase1_window<U, QM, NFIX>(bx, by, n, first + n, qp, n_bits, hi_b);
+            } else if constexpr (PARKED) {
+                // park the original rows (the exact replay reads them there), then phase 1 in place
+                u32x2 *slot = reinterpret_cast<u32x2 *>(&park[wave][lane * SVS_SLOT_DWORDS]);
+#pragma unroll
+                for (int r = 0; r < 8; ++r) slot[r] = v[r];
+                hi_a = window32(payload_qword(bits, n_words, bit_offset + first), (uint32_t)((bit_offset + first) & 31u));
+                nb_a = block_budget(first, n_bits, n);
+                und_a = embed_block_guarded2<QM, NFIX, true>(ax, ay, n, nb_a, hi_a, 0u, qp);
             } else {
                 und_a = guard_phase1<U, QM, NFIX>(ax, ay, n, first, qp, bits, bit_offset, n_bits, n_words, KEPT ? &hi_a : nullptr);
             }
@@ -765,7 +827,9 @@ __global__ __launch_bounds__(SVS_WG, kEmbedMinWaves<U>) void embed_kernel(const 
     const GuardPayload pl{bits, bit_offset, n_bits, n_words};
     const uint64_t first_a = (uint64_t)gblock * n;
     uint32_t redone;
-    if constexpr (WGPOOL) {
+    if constexpr (PARKED) {
+        redone = guard_phase2_slots<QM>(&park[wave][0], &meta[wave][0], &tiles[wave][0], lane, n, qp, und_a, nb_a, hi_a, ax, ay);
+    } else if constexpr (WGPOOL) {
         redone = guard_phase2_wg<QM, CAP, KEPT>(&entries[0][0], &tiles[wave][0], &wg_undecided, lane, wave, n, qp, pl, und_a, first_a,
                                                 ax, ay, hi_a);
         if (wave != 0) redone = 0;   // counted once per workgroup
