@@ -495,7 +495,8 @@ __global__ __launch_bounds__(SVS_WG, SVS_EXACT2_MIN_WAVES) void embed_exact_pair
 #endif
 
 // px: the block's 16 row dwords (low, high per row) in LDS - original pixels in, exact stego pixels out
-template <int QM>
+// UROWS: coefficient rows that can hold payload (n <= 8 UROWS - 1); the quantiser loop covers only those
+template <int QM, int UROWS = 8>
 __device__ __forceinline__ void guard_replay8(uint32_t *px, uint32_t hi, uint32_t lo, uint32_t nb, float *t, uint32_t r, uint32_t n,
                                               const QimParams &qp) {
     float a[8], b[8];
@@ -523,7 +524,7 @@ __device__ __forceinline__ void guard_replay8(uint32_t *px, uint32_t hi, uint32_
     // QIM on flat indices k = 8 u + r in 1..n (config_and_setup.py:139-158): one coefficient per lane and row, so a wave
     // runs n / 8 + 1 quantiser sequences, each on all the lanes that have a coefficient
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
+    for (int u = 0; u < UROWS; ++u) {
         const uint32_t k = 8u * u + r;
         if (k >= 1u && k <= n) {
             const int i = (int)k - 1;
@@ -624,7 +625,7 @@ __device__ __forceinline__ uint32_t guard_phase2(GuardEntry *entries, float *til
             const uint32_t idx = first + (lane >> 3);
             if (idx < todo) {
                 GuardEntry *e = &entries[idx];
-                guard_replay8<QM>(e->px, e->hi, e->lo, e->nb, tile + (lane >> 3) * SVS_GUARD_TILE, lane & 7u, n, qp);
+                guard_replay8<QM, 2>(e->px, e->hi, e->lo, e->nb, tile + (lane >> 3) * SVS_GUARD_TILE, lane & 7u, n, qp);
             }
         }
         wave_lds_fence();
@@ -665,7 +666,7 @@ __device__ __forceinline__ uint32_t guard_phase2_slots(uint32_t *slots, u32x2 *m
         const uint32_t idx = at + (lane >> 3);
         if (idx < total) {
             const u32x2 m = meta[idx];
-            guard_replay8<QM>(slots + (m.x & 0xffu) * SVS_SLOT_DWORDS, m.y, 0u, m.x >> 8, tile + (lane >> 3) * SVS_GUARD_TILE, lane & 7u, n, qp);
+            guard_replay8<QM, 2>(slots + (m.x & 0xffu) * SVS_SLOT_DWORDS, m.y, 0u, m.x >> 8, tile + (lane >> 3) * SVS_GUARD_TILE, lane & 7u, n, qp);
         }
     }
     wave_lds_fence();
@@ -716,7 +717,7 @@ __device__ __forceinline__ uint32_t guard_phase2_wg(GuardEntry *entries, float *
             const uint32_t idx = at + (lane >> 3);
             if (idx < todo) {
                 GuardEntry *e = &entries[idx];
-                guard_replay8<QM>(e->px, e->hi, e->lo, e->nb, tile + (lane >> 3) * SVS_GUARD_TILE, lane & 7u, n, qp);
+                guard_replay8<QM, 2>(e->px, e->hi, e->lo, e->nb, tile + (lane >> 3) * SVS_GUARD_TILE, lane & 7u, n, qp);
             }
         }
         __syncthreads();
