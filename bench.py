@@ -11,6 +11,9 @@ quoted on - 3840x2160, 600 frames, 3 AC coefficients per block, delta 8, full-ca
 With --gpus N every rank runs that batch on its own frames (weak scaling; frames are
 independent units, the only exchange is the gather of extracted bits).
 
+The timed mode is the product default ("guarded": what the drop-in operator and the video pipelines run - bit-identical to
+the reference; --mode exact selects the lane-per-block pocketfft kernels, "fast" is an alias of the default).
+
 Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (embed): algorithmic bytes
 per launch / its mean launch time measured with HIP events on the launch stream inside the timed
 region.  `cpu_baseline` (N = 1 only) times the oracle - the vectorised SciPy restatement of the

@@ -114,8 +114,8 @@ using svs::rows_for;
 //   32 tiles per XCD (+3 %).
 // * two blocks per lane (16-byte accesses) pays only for the embed kernel at one coefficient row; with
 //   more rows the extra registers cost occupancy (n = 10: -17 %).
-// Environment overrides (experiments only): SVS_EMBED_XCD_CHUNK, SVS_EXTRACT_XCD_CHUNK, SVS_EMBED_BPL,
-// SVS_EXTRACT_BPL.
+// Overrides in the experiments library only (-DSVS_EXPERIMENTS, see knob()): SVS_EMBED_XCD_CHUNK, SVS_EXTRACT_XCD_CHUNK,
+// SVS_EMBED_BPL, SVS_EXTRACT_BPL.
 constexpr uint32_t kEighth = 0xFFFFFFFFu;
 
 bool rows_allow_two_blocks(const svs_planes *p, const void *a, const void *b) {
@@ -162,7 +162,8 @@ uint32_t extract_wg_per_cu(int rows) { (void)rows; return 0; }
 
 unsigned long long *g_guard_counter = nullptr;   // measurement hook (svs_guard_counter_set): blocks redone exactly
 
-// static LDS of embed_kernel: the waves' worklists and transposition tiles
+// static LDS of the one-row embed_kernel (the waves' worklists and transposition tiles; the two-row kernel with parked rows
+// has 29 696 B): only the experiments library's occupancy-cap knob uses it
 constexpr uint32_t kEmbedLds = (SVS_WG / 64) * (SVS_GUARD_CAP * sizeof(svs::GuardEntry) + 8 * SVS_GUARD_TILE * sizeof(float));
 
 template <int QM, int BPL>

@@ -678,6 +678,11 @@ __device__ __forceinline__ uint32_t guard_phase2_slots(uint32_t *slots, u32x2 *m
     return total;
 }
 
+#ifndef SVS_U2_WGPOOL
+#define SVS_U2_WGPOOL 0      // two rows: 1 = worklist shared by the workgroup (guard_phase2_wg, A/B build only): measured SLOWER (2.74 vs
+                             // 2.65 ms per 600 x 4K, profiles/r04_ab_two_row.txt): the three barriers cost more than the passes saved
+#endif
+#if SVS_U2_WGPOOL
 // phase 2 at WORKGROUP scope (round 4; the two-row kernel, where 5-13 % of the blocks are undecided and the kernel is bound
 // by vector issue, not by HBM): the undecided blocks of all four waves share ONE worklist, and its passes of eight blocks
 // are dealt round-robin to the waves.  A wave-private worklist runs ceil(k / 8) passes for its own k blocks - 0.97 passes
@@ -731,14 +736,13 @@ __device__ __forceinline__ uint32_t guard_phase2_wg(GuardEntry *entries, float *
     return total;
 }
 
+#endif  // SVS_U2_WGPOOL
+
 // Register targets (waves per SIMD) of the embed kernels: natural allocation.  (One row: 96 VGPRs, 5 waves; spills in the
 // replay cost 1.90 vs 1.71 ms.  Two rows: 103 VGPRs, 4 waves; a target of 5 waves spills 68 B and costs 3.26 vs 2.74 ms
 // per 600 x 4K, 6 waves 4.30 ms - profiles/r04_ab_two_row.txt.)
 #ifndef SVS_KEEP_WINDOW
 #define SVS_KEEP_WINDOW 1
-#endif
-#ifndef SVS_U2_WGPOOL
-#define SVS_U2_WGPOOL 0      // two rows: 1 = worklist shared by the workgroup (guard_phase2_wg): measured SLOWER (2.74 vs 2.65 ms per 600 x 4K, profiles/r04_ab_two_row.txt): the three barriers cost more than the passes saved
 #endif
 #ifndef SVS_GUARD_CAP_WG
 #define SVS_GUARD_CAP_WG 64  // entries of the shared worklist per round (noise content: 33 undecided blocks per workgroup)
@@ -773,12 +777,14 @@ __global__ __launch_bounds__(SVS_WG, kEmbedMinWaves<U>) void embed_kernel(const 
     __shared__ u32x2 meta[PARKED ? SVS_WG / 64 : 1][PARKED ? 64 : 1];
     __shared__ GuardEntry entries[PARKED ? 1 : (WGPOOL ? 1 : SVS_WG / 64)][PARKED ? 1 : CAP];
     __shared__ float tiles[SVS_WG / 64][8 * SVS_GUARD_TILE];
-    __shared__ uint32_t wg_undecided;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+#if SVS_U2_WGPOOL
+    __shared__ uint32_t wg_undecided;
     if constexpr (WGPOOL) {
         if (threadIdx.x == 0) wg_undecided = 0u;
         __syncthreads();   // at the very start: no wave has work in flight yet
     }
+#endif
     const uint32_t gblock = (tile_id(g.xcd_chunk) * (uint32_t)SVS_WG + threadIdx.x) * BPL;
     const uint32_t n = g.n_ac;
     bool und_a = false, und_b = false, write = false;
@@ -830,10 +836,12 @@ __global__ __launch_bounds__(SVS_WG, kEmbedMinWaves<U>) void embed_kernel(const 
     uint32_t redone;
     if constexpr (PARKED) {
         redone = guard_phase2_slots<QM>(&park[wave][0], &meta[wave][0], &tiles[wave][0], lane, n, qp, und_a, nb_a, hi_a, ax, ay);
+#if SVS_U2_WGPOOL
     } else if constexpr (WGPOOL) {
         redone = guard_phase2_wg<QM, CAP, KEPT>(&entries[0][0], &tiles[wave][0], &wg_undecided, lane, wave, n, qp, pl, und_a, first_a,
                                                 ax, ay, hi_a);
         if (wave != 0) redone = 0;   // counted once per workgroup
+#endif
     } else {
         redone = guard_phase2<QM, BPL == 2, CAP, KEPT>(&entries[wave][0], &tiles[wave][0], lane, n, qp, pl, und_a, first_a, ax, ay,
                                                        und_b, first_a + n, bx, by, hi_a, hi_b);

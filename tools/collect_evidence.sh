@@ -1,12 +1,18 @@
 #!/bin/bash
-# Copy what tools/gpu/r3_evidence.sh left under gpurun_out/ev into profiles/ (run in the build container, where .git is):
-#   tools/collect_evidence.sh r03_c      -> profiles/r03_c_bench.json, ..., and the un-suffixed counter / probe / A/B files
+# Copy what tools/gpu/r4_evidence.sh left under gpurun_out/ev into profiles/ (run in the build container, where .git is):
+#   tools/collect_evidence.sh r04_c      -> profiles/r04_c_bench.json, ..., and the un-suffixed counter / probe / A/B files
+# Every kernel-stats file is headed by the commit and by the kernel-source hash bench.py computes.
 set -eu
 TAG=${1:?tag, e.g. r03_c}; ROUND=${TAG%%_*}
 cd "$(dirname "$0")/.."
 E=gpurun_out/ev; REV=$(git rev-parse --short HEAD)
 grep '^{' $E/bench.json | tail -1 > profiles/${TAG}_bench.json
-cp $E/kernel_stats.csv profiles/${TAG}_kernel_stats.csv
+SHA=$(python -c "import bench; print(bench.kernel_source_sha())")
+stats() { { echo "# commit $REV, kernel sources sha256 $SHA"; echo "# $2"; cat "$1"; } > "$3"; }
+stats $E/kernel_stats.csv "rocprofv3 --kernel-trace --stats -- python bench.py --steps 5 --warmup 2 --cpu-frames 0   (600 x 3840x2160, n = 3, delta = 8, guarded = the default mode)" profiles/${TAG}_kernel_stats.csv
+[ -f $E/kernel_stats_g10.csv ] && stats $E/kernel_stats_g10.csv "rocprofv3 --kernel-trace --stats -- python bench.py --steps 5 --warmup 2 --cpu-frames 0 --n-ac 10   (600 x 3840x2160, n = 10: the two-row rigorous kernel embed_kernel<2, QM, 1, 10> and extract_kernel<2, QM, 1, 10>)" profiles/${TAG}_kernel_stats_n10.csv
+[ -f $E/kernel_stats_g10_1080.csv ] && stats $E/kernel_stats_g10_1080.csv "same, --frames 300 --height 1080 --width 1920 (BASELINE configs[1])" profiles/${TAG}_kernel_stats_n10_1080p.csv
+[ -f $E/kernel_stats_colour_n10.csv ] && stats $E/kernel_stats_colour_n10.csv "rocprofv3 --kernel-trace --stats -- python tools/aux_rates.py 10 8   (200 x 4K BGR frames: fused colour embed embed_bgr_kernel<2, QM, false> = guarded / fast, <8, QM, true> = exact; extract_bgr_kernel)" profiles/${TAG}_kernel_stats_colour_n10.csv
 grep '^{' $E/rocprof_stats.log | tail -1 > profiles/${TAG}_bench_under_rocprof.json
 if [ -f $E/hbm_traffic.json ]; then
   sed "s/commit , tag/commit $REV, tag/" $E/hbm_traffic.json > profiles/hbm_traffic.json
@@ -15,7 +21,7 @@ fi
 for n in 3 10 63; do [ -f $E/sq_counters_n$n.txt ] && cp $E/sq_counters_n$n.txt profiles/${ROUND}_sq_counters_n$n.txt; done
 [ -f $E/other_configs_bench.jsonl ] && cp $E/other_configs_bench.jsonl profiles/${ROUND}_other_configs_bench.jsonl
 if ls $E/guarded_probe_n*.txt >/dev/null 2>&1; then
-  { for n in 3 1 7 10 15; do [ -f $E/guarded_probe_n$n.txt ] && grep -v amdgpu.ids $E/guarded_probe_n$n.txt; done; } > profiles/${ROUND}_guarded_probe.txt
+  { for n in 3 7 10 15; do [ -f $E/guarded_probe_n$n.txt ] && grep -v amdgpu.ids $E/guarded_probe_n$n.txt; done; } > profiles/${ROUND}_guarded_probe.txt
 fi
 if [ -f $E/tie_fallback_new.txt ]; then
   { echo "== this build ($REV)"; grep -v amdgpu.ids $E/tie_fallback_new.txt; echo; echo "== round-2 library (lib/variants/libsvsdct_r02.so, rebuilt from 68f741a), same box"; grep -v amdgpu.ids $E/tie_fallback_r02.txt; } > profiles/${ROUND}_tie_fallback_rate.txt
