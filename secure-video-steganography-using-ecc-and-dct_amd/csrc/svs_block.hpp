@@ -964,7 +964,10 @@ SVS_HD bool guard_decide(const uint32_t (&rx)[8], const uint32_t (&ry)[8], uint3
     return nb > 0 && !(worst < 0.5f - beta);   // nb == 0: the reference never enters the block (:130,:132)
 }
 
-// the cheap result: pixel + floor(change of its column), saturated (trunc(clip(x + c)) == clip(x + floor(c)) for integer x, :171)
+// the cheap result: pixel + floor(change of its column), saturated (trunc(clip(x + c)) == clip(x + floor(c)) for integer x, :171).
+// (Round 4 tried the add in the integer domain - column deltas packed once per block, v_pk_add_i16 + v_sat_pk_u8_i16 + v_perm_b32
+// per row dword: 128 instead of 192 instructions per block, same bytes - and measured it 6 % SLOWER in sustained bursts
+// (1.63-1.66 vs 1.54 ms per 600 x 4K, profiles/r04_ab_one_row_store.txt): this kernel is bound by HBM, not by vector issue.)
 SVS_HD void guard_apply(uint32_t (&rx)[8], uint32_t (&ry)[8], const float (&fl)[8]) {
 #define SVS_OUTCOL(X, W, B)                                                           \
     _Pragma("unroll") for (int y = 0; y < 8; ++y) W[y] = put_pixel<B>(ubyte_to_float<B>(W[y]) + fl[X], W[y]);
