@@ -232,8 +232,11 @@ int launch_extract(int rows, uint64_t total, hipStream_t st, const uint8_t *gray
             default: return fail(SVS_ERR_INVALID_ARG, "internal: rows=%d with two blocks per lane", rows);
         }
     } else {
-        switch (rows) {
-            SVS_CASE(1) SVS_CASE(2) SVS_CASE(3) SVS_CASE(4) SVS_CASE(5) SVS_CASE(6) SVS_CASE(7) SVS_CASE(8)
+        switch (rows) {   // one row takes the pocketfft-identical kernel (launch_extract_exact); SVS_FAST_EXTRACT_U1 is an experiments knob
+#if defined(SVS_EXPERIMENTS)
+            SVS_CASE(1)
+#endif
+            SVS_CASE(2) SVS_CASE(3) SVS_CASE(4) SVS_CASE(5) SVS_CASE(6) SVS_CASE(7) SVS_CASE(8)
             default: return fail(SVS_ERR_INVALID_ARG, "internal: rows=%d", rows);
         }
     }
@@ -604,11 +607,19 @@ int svs_extract_dev(const uint8_t *d_gray, const svs_planes *planes, double delt
             rc = qm == svs::QM_POW2 ? launch_extract_exact<svs::QM_POW2>(rows, total, st, d_gray, g, qp, d_bits_packed_out, bytes, two_x)
                                     : launch_extract_exact<svs::QM_F32>(rows, total, st, d_gray, g, qp, d_bits_packed_out, bytes, two_x);
         } else if (qm == svs::QM_POW2)
+#if defined(SVS_EXPERIMENTS)   // two blocks per lane in the FMA-factored extract kernels: -3 % / +1.5 % (profiles/r02_ab_extract_bpl.txt), experiments library only
             rc = tune.two_blocks ? launch_extract<svs::QM_POW2, 2>(rows, total, st, d_gray, g, qp, d_bits_packed_out, bytes)
                                  : launch_extract<svs::QM_POW2, 1>(rows, total, st, d_gray, g, qp, d_bits_packed_out, bytes);
+#else
+            rc = launch_extract<svs::QM_POW2, 1>(rows, total, st, d_gray, g, qp, d_bits_packed_out, bytes);
+#endif
         else
+#if defined(SVS_EXPERIMENTS)
             rc = tune.two_blocks ? launch_extract<svs::QM_F32, 2>(rows, total, st, d_gray, g, qp, d_bits_packed_out, bytes)
                                  : launch_extract<svs::QM_F32, 1>(rows, total, st, d_gray, g, qp, d_bits_packed_out, bytes);
+#else
+            rc = launch_extract<svs::QM_F32, 1>(rows, total, st, d_gray, g, qp, d_bits_packed_out, bytes);
+#endif
         if (rc) return rc;
     }
     if (n_bits_out) *n_bits_out = cap;

@@ -74,3 +74,19 @@ def test_kernel_source_hash_ignores_comments_and_layout_only():
     assert '"// kept /* kept */"' in bench._strip_c_comments(a)
     h = bench.kernel_source_sha()
     assert len(h) == 64 and h == bench.kernel_source_sha()
+
+
+def test_exit_rule_follows_the_oracle_not_zero():
+    """at delta = 4 or n = 63 the reference itself loses bits; the bench must fail only when the GPU's
+    errors differ from the oracle's on the sample both ran (or, without a sample, when a provably error-free setting loses one)"""
+    import bench
+    ok = {"gpu_round_trip_bit_errors_on_sample": 6584, "oracle_round_trip_bit_errors_on_sample": 6584,
+          "gpu_extract_of_reference_stego_bit_mismatches": 0}
+    assert bench.round_trip_verdict(ok, 3891153, 4.0, 3) is None                 # the reference's own 1.6 % BER, reproduced
+    assert bench.round_trip_verdict(dict(ok, gpu_round_trip_bit_errors_on_sample=6585), 0, 8.0, 3)
+    assert bench.round_trip_verdict(dict(ok, gpu_extract_of_reference_stego_bit_mismatches=1), 0, 8.0, 3)
+    assert bench.round_trip_verdict(None, 0, 8.0, 3) is None
+    assert bench.round_trip_verdict(None, 5, 8.0, 3)                             # provably error-free setting lost bits
+    assert bench.round_trip_verdict(None, 5, 8.0, 63) is None                    # clipping: the reference loses bits too
+    assert bench.round_trip_verdict(None, 5, 4.0, 3) is None
+    assert bench.round_trip_verdict(None, 5, 64.0, 3) is None                    # large steps clip
