@@ -63,6 +63,19 @@ __global__ __launch_bounds__(64) void probe(float *out, unsigned long long *cycl
             else if constexpr (KIND == 40) asm volatile("v_pk_add_i16 %0, %0, %1" : "+v"(a[i]) : "v"(c1));
             else if constexpr (KIND == 41) asm volatile("v_sad_u8 %0, %0, %1, %2" : "+v"(a[i]) : "v"(c1), "v"(c2));
             else if constexpr (KIND == 42) asm volatile("v_mov_b32 %0, %1" : "+v"(a[i]) : "v"(c1));
+            else if constexpr (KIND == 43) asm volatile("v_sat_pk_u8_i16 %0, %0" : "+v"(a[i]));
+            else if constexpr (KIND == 44) asm volatile("v_alignbit_b32 %0, %0, %1, 1" : "+v"(a[i]) : "v"(c1));
+            else if constexpr (KIND == 45) asm volatile("v_pk_max_i16 %0, %0, %1" : "+v"(a[i]) : "v"(c1));
+            else if constexpr (KIND == 46) asm volatile("v_max_u32 %0, %0, %1" : "+v"(a[i]) : "v"(c1));
+            else if constexpr (KIND == 47) asm volatile("v_or_b32 %0, %0, %1" : "+v"(a[i]) : "v"(c1));
+            else if constexpr (KIND == 48) asm volatile("v_lshlrev_b32 %0, 3, %0" : "+v"(a[i]));
+            else if constexpr (KIND == 49) asm volatile("v_cndmask_b32 %0, %0, %1, s[20:21]" : "+v"(a[i]) : "v"(c1) : "s20", "s21");
+            else if constexpr (KIND == 50) asm volatile("v_sub_f32 %0, %0, %1 clamp" : "+v"(a[i]) : "v"(c1));
+            else if constexpr (KIND == 51) asm volatile("v_mul_f32 %0, 2.0, %0" : "+v"(a[i]));
+            else if constexpr (KIND == 52) asm volatile("v_fma_f32 %0, %0, %1, %2 clamp" : "+v"(a[i]) : "v"(c1), "v"(c2));
+            else if constexpr (KIND == 53) asm volatile("v_cvt_f32_ubyte2 %0, %0" : "+v"(a[i]));
+            else if constexpr (KIND == 54) asm volatile("v_mul_u32_u24 %0, %0, %1" : "+v"(a[i]) : "v"(c1));
+            else if constexpr (KIND == 55) asm volatile("v_ashrrev_i32 %0, 3, %0" : "+v"(a[i]));
         }
     }
     const unsigned long long t1 = __builtin_readcyclecounter();
@@ -111,5 +124,9 @@ int main() {
     run<34>("v_cvt_flr_i32_f32", cus); run<35>("v_pk_fma_f16", cus); run<36>("v_med3_f32", cus); run<37>("v_xor_b32", cus);
     run<38>("v_lshl_or_b32", cus); run<39>("v_cvt_f32_u32", cus); run<40>("v_pk_add_i16", cus); run<41>("v_sad_u8", cus);
     run<42>("v_mov_b32", cus);
+    run<43>("v_sat_pk_u8_i16", cus); run<44>("v_alignbit_b32", cus); run<45>("v_pk_max_i16", cus); run<46>("v_max_u32", cus);
+    run<47>("v_or_b32", cus); run<48>("v_lshlrev_b32", cus); run<49>("v_cndmask sgpr", cus); run<50>("v_sub_f32 clamp", cus);
+    run<51>("v_mul_f32 const", cus); run<52>("v_fma_f32 clamp", cus); run<53>("v_cvt_f32_ubyte2", cus); run<54>("v_mul_u32_u24", cus);
+    run<55>("v_ashrrev_i32", cus);
     return 0;
 }
