@@ -16,9 +16,11 @@
 //   * only the coefficient rows the payload touches are transformed: flat indices 1..n live in
 //     rows u < U = n/8 + 1 of the coefficient matrix, so the vertical pass produces U outputs
 //     per column and the horizontal pass runs on U rows (template parameter U).
-//   * embed uses linearity of the DCT: stego = trunc(clip(x + IDCT(D' - D))) where D' - D is
-//     non-zero only at the n requantised coefficients; x is the exact integer pixel, so the
-//     only rounding in the output is that of the (sparse) inverse transform.
+//   * the streaming embed (n <= 15) uses linearity of the DCT as a PREDICTION: trunc(clip(x + IDCT(D' - D))), where D' - D
+//     is non-zero only at the n requantised coefficients and x is the exact integer pixel, is the reference's byte wherever
+//     a rigorous bound on the reference's own float32 round-trip noise (BETA, tools/guard_bound.py) separates the predicted
+//     value from the integer grid; the other blocks are redone with pocketfft's exact operation sequence (namespace pf).
+//   * everything else (n >= 16, delta outside the guard's range, the "exact" mode) replays pocketfft on all 64 coefficients.
 #pragma once
 #include <math.h>
 #include <stdint.h>
@@ -822,7 +824,7 @@ SVS_HD void forward_exact_paired_constant(float v, pf::f32x2 (&D2)[4][8]) {
 }
 
 // `constant_block`: the caller knows (wave-uniformly) that all 64 pixels are equal - the forward pass is then the two-line
-// shortcut above (used by the replay pass of FAST embedding, where whole letterbox bars arrive)
+// shortcut above (host emulation of flat content; the device replay transforms every block in full)
 template <int U, int QM>
 SVS_HD void embed_block_exact(uint32_t (&rx)[8], uint32_t (&ry)[8], uint32_t n, uint32_t nb, uint32_t hi, uint32_t lo,
                               const QimParams &qp, bool constant_block = false) {
@@ -877,7 +879,8 @@ SVS_HD void embed_block_exact(uint32_t (&rx)[8], uint32_t (&ry)[8], uint32_t n, 
 }
 
 // =====================================================================================================
-// GUARDED mode: the reference's stego pixels, bit for bit, at the cost of the FAST path for almost every block.
+// The streaming embed arithmetic (n <= 15; every mode): the reference's stego pixels, bit for bit, at the cost of a cheap
+// sparse transform for almost every block.
 //
 // The reference's output for a block is trunc(clip(out)), out = pf_dct3(pf_dct3(D')) in float32 (config_and_setup.py:
 // 166-171).  embed_block_guarded computes, with a handful of operations,
@@ -991,7 +994,7 @@ SVS_HD bool embed_block_guarded(uint32_t (&rx)[8], uint32_t (&ry)[8], uint32_t n
 // down a column) - pocketfft-identical rows 0 and 1, QIM with the reference's decisions, sparse inverse, and every pixel's
 // prediction tested against the grid with the bound of ITS position: the (2 -> 1) norms behind KE differ by pixel (24.7 in
 // rows / columns 0, 3, 4, 7 crossed with each other, 31.0 in rows / columns 1, 2, 5, 6 crossed, 27.9 mixed), which takes the
-// share of undecided noise blocks from 13 % to 12 %.  FAST and GUARDED both run it (round 4).
+// share of undecided noise blocks from 13 % to 12 %.  Every mode runs it (round 4: flags 0 and SVS_EXACT_GUARDED are the same launch).
 #define SVS_GUARD_KE_CC 24.68
 #define SVS_GUARD_KE_CE 27.93
 

@@ -468,7 +468,7 @@ __global__ __launch_bounds__(SVS_WG, SVS_EXACT2_MIN_WAVES) void embed_exact_pair
 }
 
 // ---------------------------------------------------------------------------------------
-// EMBED (FAST and GUARDED modes, include/svsdct.h): one lane = BPL adjacent blocks, grid = ceil(total_blocks / (SVS_WG*BPL))
+// EMBED, streaming kernel (n <= 15; flags 0 and SVS_EXACT_GUARDED, include/svsdct.h): one lane = BPL adjacent blocks, grid = ceil(total_blocks / (SVS_WG*BPL))
 // workgroups of SVS_WG.  BPL = 2 (16-byte row accesses) needs an even number of blocks per row and 16-byte aligned rows
 // (the host checks) and is instantiated for one coefficient row only.
 // HBM traffic per block: 64 B read + 64 B written + n payload bits read - nothing else, whatever the content.
@@ -1206,7 +1206,7 @@ __global__ __launch_bounds__(SVS_WG) void embed_bgr_kernel(const uint8_t *bgr_in
                                                         const Geometry g, const ColourParams c, const QimParams qp,
                                                         const uint32_t *__restrict__ bits, const uint64_t bit_offset,
                                                         const uint64_t n_bits, const uint32_t n_words) {
-    // one wave-private 4 KB region per wave: row staging of the cooperative load, then (FAST) the worklist and transposition
+    // one wave-private 4 KB region per wave: row staging of the cooperative load, then (streaming arithmetic) the worklist and transposition
     // tile of the exact replay (svs::guard_phase2, 16 entries per round), then the stego tile of the cooperative store
     __shared__ __attribute__((aligned(16))) u32x2 lds_tile[SVS_WG / 64][8][64];
     static_assert(16 * sizeof(GuardEntry) + 8 * SVS_GUARD_TILE * sizeof(float) <= 8 * 64 * sizeof(u32x2), "wave region too small");
@@ -1215,7 +1215,7 @@ __global__ __launch_bounds__(SVS_WG) void embed_bgr_kernel(const uint8_t *bgr_in
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const bool live = gblock < g.total_blocks;
     uint32_t ax[8], ay[8];
-    // cooperative load, four rows at a time: +5..7 % over per-lane loads at a 24-byte stride in FAST mode (62 -> 78 VGPRs),
+    // cooperative load, four rows at a time: +5..7 % over per-lane loads at a 24-byte stride with the streaming arithmetic (62 -> 78 VGPRs),
     // neutral in EXACT mode; all eight rows at once cost 100+ VGPRs and gained 1 % (profiles/r01_aux_kernel_rates.txt)
     wave_load_gray_halves(bgr_in, g, c, gblock - lane, lane, &lds_tile[wave][0][0], ax, ay);
     bool und = false;
