@@ -850,20 +850,24 @@ int svs_extract_bgr_dev(const uint8_t *d_bgr, int64_t bgr_row_pitch, int64_t bgr
         g.xcd_chunk = knob("SVS_EXTRACT_XCD_CHUNK", rows_for(n) == 1 ? 32u : kEighth);
         const dim3 grid((uint32_t)((total + SVS_WG - 1) / SVS_WG));
         const int rows = rows_for(n);
+        // tiny steps: the rounding constant of the two-step extraction needs |c / delta| < 2^22 (as in svs_extract_dev)
+        const bool fastx = (double)qp.delta_f >= SVS_FAST_EXTRACT_DELTA_MIN;
+#define SVS_LAUNCH(R, QMV, FX)                                                                                               \
+    hipLaunchKernelGGL((svs::extract_bgr_kernel<R, QMV, FX>), grid, dim3(SVS_WG), 0, st, d_bgr, g, c, qp, d_bits_packed_out, bytes)
 #define SVS_CASE(R)                                                                                                      \
     case R:                                                                                                              \
-        if (qm == svs::QM_POW2)                                                                                          \
-            hipLaunchKernelGGL((svs::extract_bgr_kernel<R, svs::QM_POW2>), grid, dim3(SVS_WG), 0, st, d_bgr, g, c, qp,   \
-                               d_bits_packed_out, bytes);                                                                \
-        else                                                                                                             \
-            hipLaunchKernelGGL((svs::extract_bgr_kernel<R, svs::QM_F32>), grid, dim3(SVS_WG), 0, st, d_bgr, g, c, qp,    \
-                               d_bits_packed_out, bytes);                                                                \
+        if (R >= 2 && fastx) {                                                                                           \
+            if (qm == svs::QM_POW2) SVS_LAUNCH(R, svs::QM_POW2, (R >= 2)); else SVS_LAUNCH(R, svs::QM_F32, (R >= 2));    \
+        } else {                                                                                                         \
+            if (qm == svs::QM_POW2) SVS_LAUNCH(R, svs::QM_POW2, false); else SVS_LAUNCH(R, svs::QM_F32, false);          \
+        }                                                                                                                \
         break;
         switch (rows) {
             SVS_CASE(1) SVS_CASE(2) SVS_CASE(3) SVS_CASE(4) SVS_CASE(5) SVS_CASE(6) SVS_CASE(7) SVS_CASE(8)
             default: return fail(SVS_ERR_INVALID_ARG, "internal: rows=%d", rows);
         }
 #undef SVS_CASE
+#undef SVS_LAUNCH
         SVS_HIP(hipGetLastError());
     }
     if (n_bits_out) *n_bits_out = cap;

@@ -1252,35 +1252,39 @@ __global__ __launch_bounds__(SVS_WG) void embed_bgr_kernel(const uint8_t *bgr_in
     wave_store_gray_as_bgr(&lds_tile[wave][0][0], lane, gblock, live, ax, ay, bgr_out, g, c);
 }
 
-// extract straight from interleaved BGR frames (gray computed on the fly; pocketfft-identical forward)
-template <int U, int QM>
+// extract straight from interleaved BGR frames (gray computed on the fly).  One coefficient row: pocketfft-identical forward;
+// two and more rows (round 4): the two-step FAST extraction of extract_kernel - FMA-factored forward, wave ballot of near-tie
+// candidates, pocketfft coefficient 4 + per-block margin, 8-lane exact replay of tie blocks - instead of the pocketfft forward
+// of every row for every block (0.88 ms per 200 x 4K BGR frames at n = 10 against an HBM floor of 0.75).
+// FASTX = false keeps the pocketfft forward (delta below SVS_FAST_EXTRACT_DELTA_MIN).
+template <int U, int QM, bool FASTX = (U >= 2)>
 __global__ __launch_bounds__(SVS_WG) void extract_bgr_kernel(const uint8_t *__restrict__ bgr, const Geometry g,
                                                           const ColourParams c, const QimParams qp,
                                                           uint8_t *__restrict__ out, const uint64_t out_bytes) {
     __shared__ uint32_t flags[SVS_WG / 64][SVS_WAVE_BITS_DWORDS(1)];
+    __shared__ __attribute__((aligned(16))) u32x2 rows[SVS_WG / 64][2 * 192];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t tile = tile_id(g.xcd_chunk);
     const uint32_t gblock = tile * (uint32_t)SVS_WG + threadIdx.x;
     const uint32_t n = g.n_ac;
     uint32_t hi = 0, lo = 0;
     uint32_t ax[8], ay[8];
-#if !defined(SVS_BGR_DIRECT_LOAD)
-    __shared__ __attribute__((aligned(16))) u32x2 rows[SVS_WG / 64][2 * 192];
     const WaveUnits wu = wave_units(lane, gblock - lane, g.total_blocks);
     wave_load_gray(bgr, g, c, wu, gblock - lane, lane, &rows[wave][0], ax, ay);
-    if (gblock < g.total_blocks) extract_block_exact<U, QM>(ax, ay, n, qp, hi, lo);
-#else
-    if (gblock < g.total_blocks) {
-        const uint8_t *src = bgr + block_offset_bgr(gblock, g, c.in_row_pitch, c.in_frame_pitch);
-#pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            u32x2 q0, q1, q2;
-            load_bgr_row(src + r * c.in_row_pitch, q0, q1, q2);
-            bgr8_to_gray(q0, q1, q2, c, ax[r], ay[r]);
+    if constexpr (FASTX) {
+        __shared__ GuardEntry entries[SVS_WG / 64][SVS_EXTRACT_CAP];
+        __shared__ float tiles[SVS_WG / 64][8 * SVS_GUARD_TILE];
+        bool tie = false;
+        float off = 0.0f;
+        if (gblock < g.total_blocks) tie = extract_block_cheap<U, QM>(ax, ay, n, qp, hi, lo, off);    // -> candidate
+        if (__ballot(tie) != 0) {
+            if (gblock < g.total_blocks) tie = extract_block_settle<QM>(ax, ay, n, qp, hi, off);
         }
-        extract_block_exact<U, QM>(ax, ay, n, qp, hi, lo);
+        uint32_t hb = 0, lb = 0;
+        extract_phase2<QM, false, SVS_EXTRACT_CAP>(&entries[wave][0], &tiles[wave][0], lane, n, qp, tie, ax, ay, hi, lo, false, ax, ay, hb, lb);
+    } else {
+        if (gblock < g.total_blocks) extract_block_exact<U, QM>(ax, ay, n, qp, hi, lo);
     }
-#endif
     emit_wave_bits<U, 1>(&flags[wave][0], lane, (uint64_t)tile * (uint32_t)SVS_WG + wave * 64u, n, hi, lo, 0u, 0u, out,
                          out_bytes);
 }

@@ -732,6 +732,16 @@ def test_fused_colour_embed_equals_convert_embed_convert(mode):
             src_gray = np.stack([d_gray_default(x) for x in src])
             assert n_bits == cap
             assert np.array_equal(np.unpackbits(packed, count=n_bits), orc.batch_extract_bits(src_gray, delta, n_ac))
+    # extraction straight from never-embedded colour frames of real size (round 4: the fused extract kernel takes the two-step
+    # FAST extraction for n >= 8 - candidates, pocketfft coefficient 4, per-block margin, 8-lane replay of tie blocks): ties of
+    # c / delta are frequent on covers (1 block in 8 delta at flat index 4), every bit must be the oracle's
+    if mode == "guarded":
+        big = rng.integers(0, 256, (2, 272, 480, 3), dtype=np.uint8)
+        big[1] = np.repeat(rng.integers(0, 256, (272, 480, 1), dtype=np.uint8), 3, axis=2)      # gray content in BGR
+        big_gray = np.stack([d_gray_default(x) for x in big])
+        for n_ac, delta in ((10, 8), (10, 1), (15, 20), (20, 8), (40, 4), (9, 0.0005)):
+            packed, n_bits = batch.extract_bgr_frames(big, delta, n_ac)
+            assert np.array_equal(np.unpackbits(packed, count=n_bits), orc.batch_extract_bits(big_gray, delta, n_ac)), (n_ac, delta)
     # custom weight table + no gray reference + empty payload (frames are just converted)
     bgr = rng.integers(0, 256, (1, 40, 48, 3), dtype=np.uint8)
     w14 = np.array([1868, 9617, 4899, 14], np.uint32)

@@ -14,6 +14,7 @@ stats $E/kernel_stats.csv "rocprofv3 --kernel-trace --stats -- python bench.py -
 [ -f $E/kernel_stats_g10_1080.csv ] && stats $E/kernel_stats_g10_1080.csv "same, --frames 300 --height 1080 --width 1920 (BASELINE configs[1])" profiles/${TAG}_kernel_stats_n10_1080p.csv
 [ -f $E/kernel_stats_colour_n10.csv ] && stats $E/kernel_stats_colour_n10.csv "rocprofv3 --kernel-trace --stats -- python tools/aux_rates.py 10 8   (200 x 4K BGR frames: fused colour embed embed_bgr_kernel<2, QM, false> = guarded / fast, <8, QM, true> = exact; extract_bgr_kernel)" profiles/${TAG}_kernel_stats_colour_n10.csv
 grep '^{' $E/rocprof_stats.log | tail -1 > profiles/${TAG}_bench_under_rocprof.json
+[ -f $E/rocprof_stats_colour.log ] && { echo "# commit $REV: python tools/aux_rates.py 10 8 (200 x 4K frames; run under rocprofv3 --kernel-trace --stats, whose kernel table is ${TAG}_kernel_stats_colour_n10.csv)"; grep -E "GB/s|fused|--" $E/rocprof_stats_colour.log | grep -v amdgpu; } > profiles/${ROUND}_aux_kernel_rates.txt
 if [ -f $E/hbm_traffic.json ]; then
   sed "s/commit , tag/commit $REV, tag/" $E/hbm_traffic.json > profiles/hbm_traffic.json
   sed "s/commit , tag/commit $REV, tag/" $E/${ROUND}_pmc_summary.json > profiles/${ROUND}_pmc_summary.json
