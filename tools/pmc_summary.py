@@ -15,7 +15,7 @@ sys.path.insert(0, repo)
 from bench import kernel_source_sha      # what bench.py compares the capture against
 src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(repo, "gpurun_out")
 tag = sys.argv[2] if len(sys.argv) > 2 else "r03"
-F, H, W, n = 600, 2160, 3840, 3
+F, H, W, n = 600, 2160, 3840, int(sys.argv[3]) if len(sys.argv) > 3 else 3     # n != 3: summary only, hbm_traffic.json is left alone
 agg = collections.defaultdict(list)
 for f in glob.glob(os.path.join(src, "pmc_*", "*", "*_counter_collection.csv")):
     for r in csv.DictReader(open(f)):
@@ -54,7 +54,8 @@ captured = f"{datetime.date.today().isoformat()}, commit {rev}, tag {tag}"
 out["captured"] = captured
 with open(os.path.join(repo, "profiles", f"{tag}_pmc_summary.json"), "w") as fh:
     json.dump(out, fh, indent=1, sort_keys=True)
-with open(os.path.join(repo, "profiles", "hbm_traffic.json"), "w") as fh:
+if n == 3:
+  with open(os.path.join(repo, "profiles", "hbm_traffic.json"), "w") as fh:
     json.dump({"frames": F, "height": H, "width": W, "n_ac": n,
                "embed_bytes_per_launch": out["kernels"]["embed_kernel"]["hbm_bytes_per_launch"],
                "captured": captured, "kernel_source_sha256": kernel_source_sha(),
