@@ -36,7 +36,7 @@ HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB
 SEED = 20250620
 
 
-def parse_args():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
@@ -62,7 +62,35 @@ def parse_args():
     ap.add_argument("--force-dist", action="store_true",
                     help="take the process-group path (RCCL gather included) even with one rank, so that a one-GPU box "
                          "exercises the collective calls")
-    return ap.parse_args()
+    return ap.parse_args(argv)
+
+
+def job_plan(args, world: int) -> dict:
+    """Who does what in a `world`-rank run of these arguments - pure arithmetic, no GPU, no torch (main() runs on it, and the
+    CPU test tier dry-runs the documented multi-GPU commands through it): per-rank frame shares (contiguous, rank order =
+    stream order), each rank's offset into the job's bit stream, the bytes every rank contributes to the gather (equal sizes:
+    the largest share's packed bits) and the device memory a rank needs."""
+    from svsdct import batch
+    H, W, n_ac = args.height, args.width, args.n_ac
+    if args.total_frames > 0:        # strong scaling: one clip divided over the ranks
+        shares = [batch.shard_frames(args.total_frames, world, r) for r in range(world)]
+    else:                            # weak scaling: every rank runs the N = 1 batch on its own frames
+        shares = [(r * args.frames, args.frames) for r in range(world)]
+    per_frame_bits = batch.capacity_bits(1, H, W, n_ac)
+    gather_bytes = (max(c for _, c in shares) * per_frame_bits + 7) // 8
+    ranks = []
+    for first, count in shares:
+        cap = count * per_frame_bits
+        nbytes = (cap + 7) // 8
+        ranks.append({"first_frame": first, "frames": count, "first_bit": first * per_frame_bits, "capacity_bits": cap,
+                      "blocks": count * (H // 8) * (W // 8),
+                      # gray + stego (+ the exact-mode stego rank 0 adds after the timed region) + payload + two extract buffers
+                      "device_bytes": 3 * count * H * W + nbytes + 2 * max(nbytes, gather_bytes) + 64,
+                      "embed_algorithmic_bytes": 2 * count * H * W + nbytes, "extract_algorithmic_bytes": count * H * W + nbytes})
+    return {"world": world, "scaling": "strong" if args.total_frames > 0 else "weak", "shares": shares,
+            "per_frame_bits": per_frame_bits, "gather_bytes_per_rank": gather_bytes,
+            "bytes_received_by_rank0_per_step": world * gather_bytes if world > 1 else 0,
+            "total_frames": sum(c for _, c in shares), "ranks": ranks}
 
 
 def launch_ranks(args) -> int:
@@ -226,13 +254,11 @@ def main():
     native.ensure_device(local_rank)
 
     H, W, n_ac, delta = args.height, args.width, args.n_ac, args.delta
-    if args.total_frames > 0:        # strong scaling: this rank's contiguous share of the clip
-        first_frame, F = batch.shard_frames(args.total_frames, world, rank)
-        if F == 0:
-            raise SystemExit(f"--total-frames {args.total_frames} leaves rank {rank} of {world} without frames")
-    else:                            # weak scaling: every rank runs the N = 1 batch on its own frames
-        first_frame, F = rank * args.frames, args.frames
-    mode = args.mode or os.environ.get("SVS_DCT_MODE") or "guarded"      # the product default (svsdct.batch, drop-in modules)
+    plan = job_plan(args, world)
+    first_frame, F = plan["shares"][rank]
+    if F == 0:
+        raise SystemExit(f"--total-frames {args.total_frames} leaves rank {rank} of {world} without frames")
+    mode = batch.resolve_mode(args.mode)     # unspecified = svsdct.batch.DEFAULT_MODE, what the drop-in operator and video loops run
     planes = Planes.contiguous(F, H, W)
     cap = batch.capacity_bits(F, H, W, n_ac)
     nbytes = (cap + 7) // 8
@@ -241,13 +267,12 @@ def main():
     gray = torch.empty((F, H, W), dtype=torch.uint8, device=dev)
     stego = torch.empty_like(gray)
     payload = torch.zeros(nbytes + 8 - nbytes % 4, dtype=torch.uint8, device=dev)
-    per_frame_bits = batch.capacity_bits(1, H, W, n_ac)
-    first_bit = first_frame * per_frame_bits                 # this rank's offset in the job's bit stream
+    per_frame_bits = plan["per_frame_bits"]
+    first_bit = plan["ranks"][rank]["first_bit"]             # this rank's offset in the job's bit stream
     # dist.gather wants equal sizes: every rank contributes the packed bits of the LARGEST share (ranks differ by at most one
     # frame under --total-frames; the tail of a smaller share is padding the check below ignores)
-    shares = [batch.shard_frames(args.total_frames, world, r) for r in range(world)] if args.total_frames > 0 else \
-             [(r * args.frames, args.frames) for r in range(world)]
-    gather_bytes = (max(c for _, c in shares) * per_frame_bits + 7) // 8
+    shares = plan["shares"]
+    gather_bytes = plan["gather_bytes_per_rank"]
     # extracted bits are double-buffered so that the gather of step k overlaps the kernels of step k+1
     ext_len = max(nbytes, gather_bytes)
     ext_bufs = [torch.zeros(ext_len + 8 - ext_len % 4, dtype=torch.uint8, device=dev) for _ in range(2 if use_dist else 1)]
@@ -429,12 +454,18 @@ def main():
                         "note": "asynchronous: the gather of step k runs beside the kernels of step k + 1; the wait is what "
                                 "is left when its buffer is needed again (and at the end of the timed region)"}
                        if use_dist else None),
-            "roofline": {"bound": "hbm", "kernel": ("embed_exact_kernel (lane-per-block pocketfft arithmetic)" if mode == "exact" or (mode == "guarded" and n_ac > 15)
+            "roofline": {"bound": "hbm", "kernel": ("embed_exact_kernel (lane-per-block pocketfft arithmetic)" if mode == "exact" or n_ac > 15
                                                     else "embed_kernel (one launch: cheap arithmetic + in-kernel exact replay of undecided blocks)"),
                          "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "algorithmic_bytes_per_launch": embed_bytes,
-                         "extract_achieved": extract_bytes / (extract_ms * 1e-3) / 1e9},
+                         "extract_achieved": extract_bytes / (extract_ms * 1e-3) / 1e9,
+                         # every rank's own embed launch against ITS algorithmic bytes (shares differ by at most one frame)
+                         "per_rank": [{"rank": r, "frames": plan["ranks"][r]["frames"],
+                                       "achieved": plan["ranks"][r]["embed_algorithmic_bytes"] / (per_rank[r][0] * 1e-3) / 1e9,
+                                       "frac": plan["ranks"][r]["embed_algorithmic_bytes"] / (per_rank[r][0] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                       "extract_achieved": plan["ranks"][r]["extract_algorithmic_bytes"] / (per_rank[r][1] * 1e-3) / 1e9}
+                                      for r in range(world)]},
         }
         if gather_ok is not None:
             result["gather_ok"] = gather_ok      # every rank's slice of the gathered stream equals its payload
@@ -499,11 +530,11 @@ def main():
             "value": crop.size / t_loop / 1e6, "unit": "Mpix/s", "cores": 1, "kind": "port",
             "sample": f"one 320x240 crop, embed + extract in {t_loop:.2f} s: per-block Python loop with scipy.fftpack calls, "
                       f"the shape of the reference's own code (context only)"}
-        # the other direction: the GPU (fast mode) reading the ORACLE's stego frames must give the oracle's bits
+        # the other direction: the GPU (the timed mode) reading the ORACLE's stego frames must give the oracle's bits
         ref_dev = torch.from_numpy(ref_stego).to(dev)
         planes_m = Planes.contiguous(m, H, W)
         batch.extract_device(ref_dev.data_ptr(), planes_m, delta, n_ac, extracted.data_ptr(), extracted.numel(), stream,
-                             mode="fast")
+                             mode=mode)
         torch.cuda.synchronize()
         got_bits = np.unpackbits(extracted[: (m * per + 7) // 8].cpu().numpy(), count=m * per)
         gpu_sample_bits = np.unpackbits(gpu_sample_packed.cpu().numpy(), count=m * per)   # what the timed extract returned

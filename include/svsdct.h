@@ -17,7 +17,11 @@
  *   - the caller owns every buffer.  `*_dev` entry points take DEVICE pointers and a
  *     hipStream_t (as void*; NULL = the null stream), enqueue work and return without
  *     synchronising.  The entry points without the suffix take HOST pointers, stage through
- *     device memory and return when the result is in the host buffers.
+ *     device memory and return when the result is in the host buffers: the frames travel in
+ *     chunks over the upload and the download stream of a per-thread staging context (upload of
+ *     chunk k+1 beside the download of chunk k: the link is full duplex), nothing is allocated per call once the context has grown to the
+ *     largest call, and a page-locked caller buffer (svs_host_alloc) is the DMA's own
+ *     source / target - pageable memory goes through the context's pinned rings.
  *   - frames are gray uint8 planes, H and W multiples of 8 (the reference's callers crop:
  *     embed_process.py:94,113; extract_process.py:34,62), laid out [frame][row][col] with byte
  *     pitches given in svs_planes.
@@ -42,7 +46,7 @@
 extern "C" {
 #endif
 
-#define SVS_ABI_VERSION 3
+#define SVS_ABI_VERSION 4
 
 #define SVS_OK 0
 #define SVS_ERR_INVALID_ARG (-1)  /* bad geometry / NULL pointer / size overflow */
@@ -107,6 +111,11 @@ int svs_device_count(int *count);
 int svs_init(int device);
 /* Name of the architecture the device reports, e.g. "gfx950". */
 int svs_device_arch(int device, char *buf, size_t buf_len);
+/* Releases the CALLING THREAD's staging context of the host-pointer entry points (svs_embed, svs_extract, svs_embed_bgr,
+ * svs_extract_bgr): two streams, grow-only device buffers as large as the largest call the thread has made, two rings of
+ * pinned staging slots.  A thread's context is also released when the thread exits; calling any host-pointer entry point
+ * afterwards simply builds a new one.  The *_dev entry points keep nothing. */
+int svs_shutdown(void);
 
 /* ---- device memory / stream helpers for callers that do not bring their own ------------- */
 int svs_malloc(void **dev_ptr, size_t bytes);
@@ -154,6 +163,15 @@ int svs_embed(const uint8_t *gray, uint8_t *stego, const svs_planes *planes,
               const uint8_t *bits_packed, uint64_t bit_offset, uint64_t n_bits,
               uint32_t flags, uint64_t *n_embedded);
 
+/* The same call with the payload in the reference operator's own form: `bit_payload_segment`, a string of '0' / '1'
+ * characters (config_and_setup.py:106-109,124-126; one character per bit, no terminator needed).  n_chars characters are
+ * available, min(n_chars, capacity) are read - a frame loop may hand over the whole remaining payload as the reference does
+ * (embed_process.py:116-121) - and are packed on the device.  n_chars > 0 with nothing embeddable (delta <= 0, n_ac <= 0)
+ * still round-trips every block, n_chars = 0 (or NULL) copies the frames, as in the reference. */
+int svs_embed_str(const uint8_t *gray, uint8_t *stego, const svs_planes *planes,
+                  double delta, int n_ac, const char *bits_ascii, uint64_t n_chars,
+                  uint32_t flags, uint64_t *n_embedded);
+
 /* ---- the operator: extract ----------------------------------------------------------------
  * Replaces mode 'extract' (config_and_setup.py:159-165,173-174) for a whole batch and the
  * concatenation of extract_process.py:76,181.
@@ -169,6 +187,12 @@ int svs_extract_dev(const uint8_t *d_gray, const svs_planes *planes, double delt
 int svs_extract(const uint8_t *gray, const svs_planes *planes, double delta, int n_ac,
                 uint8_t *bits_packed_out, uint64_t out_capacity_bytes, uint32_t flags,
                 uint64_t *n_bits_out);
+
+/* Extraction into the reference operator's own return type: the '0' / '1' string of config_and_setup.py:173-174, one
+ * character per bit (no terminator is written).  bits_ascii_out receives capacity characters; out_capacity_chars is its size. */
+int svs_extract_str(const uint8_t *gray, const svs_planes *planes, double delta, int n_ac,
+                    char *bits_ascii_out, uint64_t out_capacity_chars, uint32_t flags,
+                    uint64_t *n_bits_out);
 
 /* ---- colour plumbing around the operator (device resident) --------------------------------------------
  * Interleaved 8-bit BGR frames [frame][row][col][3] <-> gray planes.  bgr_row_pitch / bgr_frame_pitch in bytes,

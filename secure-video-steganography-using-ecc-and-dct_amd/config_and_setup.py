@@ -14,6 +14,7 @@ import os
 import numpy as np
 
 from svsdct import batch as _batch
+from svsdct.hostmem import pinned_copy as _pinned_copy
 
 _HKDF_INFO = b"kunci aes untuk steganografi video"  # reference config_and_setup.py:94
 _GCM_TAG_BYTES = 16
@@ -97,20 +98,19 @@ def proses_frame_qim_dct(frame_bgr_input, mode, delta,
     if frame.ndim == 3 and frame.shape[2] == 3:
         gray = _bgr_to_gray(frame)
     elif frame.ndim == 2:
-        gray = frame.copy()
+        # the reference's `.copy()` (:114) - made into page-locked memory, so the copy the contract asks for is also the
+        # staging copy: the upload reads it by DMA (svsdct.hostmem)
+        gray = _pinned_copy(frame) if frame.dtype == np.uint8 and frame.size else frame.copy()
     else:
         raise ValueError("Format frame input tidak didukung.")
     gray = np.ascontiguousarray(gray, np.uint8)
     if mode == "embed":
-        h, w = gray.shape
-        cap = _batch.capacity_bits(1, h, w, num_ac_coeffs_to_use)
-        # the operator receives the whole remaining payload but reads at most `cap` characters
-        bits = _batch.str_to_bits(bit_payload_segment, cap) if bit_payload_segment else np.zeros(0, np.uint8)
-        stego, used = _batch.embed_frames(gray, delta, num_ac_coeffs_to_use, bits)
+        # the operator receives the whole remaining payload as a '0'/'1' string and reads at most the capacity; the library
+        # takes the string as it is (svs_embed_str).  None / "" = nothing to embed: the frame is copied (:124-126)
+        stego, used = _batch.embed_frames_str(gray, delta, num_ac_coeffs_to_use, bit_payload_segment)
         return gray, stego[0], used
     if mode == "extract":
-        packed, n_bits = _batch.extract_frames(gray, delta, num_ac_coeffs_to_use)
-        return _batch.unpack_to_str(packed, n_bits)
+        return _batch.extract_frames_str(gray, delta, num_ac_coeffs_to_use)
     return None
 
 

@@ -160,7 +160,15 @@ Tuning extract_tuning(int rows, const svs_planes *p, const void *a) {
 uint32_t embed_wg_per_cu(int rows, int bpl) { (void)rows; (void)bpl; return 0u; }
 uint32_t extract_wg_per_cu(int rows) { (void)rows; return 0; }
 
-unsigned long long *g_guard_counter = nullptr;   // measurement hook (svs_guard_counter_set): blocks redone exactly
+// Measurement hook of the EXPERIMENTS library only (svs_guard_counter_set): a device counter the streaming embed launches add
+// the number of blocks they redid exactly to.  The product library has neither the global nor the kernel parameter: no state
+// survives a call (include/svsdct.h).
+#if defined(SVS_EXPERIMENTS)
+unsigned long long *g_guard_counter = nullptr;
+#define SVS_COUNTER_ARG , g_guard_counter
+#else
+#define SVS_COUNTER_ARG
+#endif
 
 // static LDS of the one-row embed_kernel (the waves' worklists and transposition tiles; the two-row kernel with parked rows
 // has 29 696 B): only the experiments library's occupancy-cap knob uses it
@@ -171,12 +179,14 @@ int launch_embed(int rows, uint64_t total, hipStream_t st, const uint8_t *gray, 
                  const svs::QimParams &qp, const uint32_t *bits, uint64_t bit_offset, uint64_t n_bits,
                  uint32_t n_words) {
     const dim3 grid((uint32_t)((total + SVS_WG * BPL - 1) / (SVS_WG * BPL)));
-    const uint32_t lds_pad = lds_pad_for(knob("SVS_EMBED_WG_PER_CU", embed_wg_per_cu(rows, BPL)), kEmbedLds);
+    // (the occupancy cap is an experiments knob; the two-row kernel's parked form has 29 696 B of static LDS, the others kEmbedLds)
+    const uint32_t lds_pad = lds_pad_for(knob("SVS_EMBED_WG_PER_CU", embed_wg_per_cu(rows, BPL)),
+                                         rows == 2 && QM != svs::QM_POW2 ? 29696u : kEmbedLds);
     if constexpr (BPL == 1) {
         // n = 10 (the reference GUI's default, app.py:69; BASELINE configs[1]) has a compile-time-n instantiation of the two-row kernel
-        if (g.n_ac == 10 && knob("SVS_FIXED_N", 1) != 0) {
+        if (rows == 2 && g.n_ac == 10 && knob("SVS_FIXED_N", 1) != 0) {
             hipLaunchKernelGGL((svs::embed_kernel<2, QM, 1, 10>), grid, dim3(SVS_WG), lds_pad, st, gray, stego, g, qp, bits, bit_offset,
-                               n_bits, n_words, g_guard_counter);
+                               n_bits, n_words SVS_COUNTER_ARG);
             SVS_HIP(hipGetLastError());
             return SVS_OK;
         }
@@ -185,24 +195,24 @@ int launch_embed(int rows, uint64_t total, hipStream_t st, const uint8_t *gray, 
     if constexpr (BPL == 2) {
         if (rows == 1)
             hipLaunchKernelGGL((svs::embed_kernel<1, QM, 2>), grid, dim3(SVS_WG), lds_pad, st, gray, stego, g, qp, bits, bit_offset, n_bits,
-                               n_words, g_guard_counter);
+                               n_words SVS_COUNTER_ARG);
 #if SVS_U2_BPL == 2   // A/B build only: two adjacent blocks per lane with a joint replay need 150 VGPRs (3 waves per SIMD) and end
                       // level with one block per lane (2.57 vs 2.57 ms per 600 x 4K, profiles/r04_ab_two_row.txt)
         else if (g.n_ac == 10)
             hipLaunchKernelGGL((svs::embed_kernel<2, QM, 2, 10>), grid, dim3(SVS_WG), lds_pad, st, gray, stego, g, qp, bits, bit_offset, n_bits,
-                               n_words, g_guard_counter);
+                               n_words SVS_COUNTER_ARG);
         else
             hipLaunchKernelGGL((svs::embed_kernel<2, QM, 2>), grid, dim3(SVS_WG), lds_pad, st, gray, stego, g, qp, bits, bit_offset, n_bits,
-                               n_words, g_guard_counter);
+                               n_words SVS_COUNTER_ARG);
 #else
         else return fail(SVS_ERR_INVALID_ARG, "internal: rows=%d with two blocks per lane", rows);
 #endif
     } else if (rows == 1) {
         hipLaunchKernelGGL((svs::embed_kernel<1, QM, 1>), grid, dim3(SVS_WG), lds_pad, st, gray, stego, g, qp, bits, bit_offset, n_bits,
-                           n_words, g_guard_counter);
+                           n_words SVS_COUNTER_ARG);
     } else {
         hipLaunchKernelGGL((svs::embed_kernel<2, QM, 1>), grid, dim3(SVS_WG), lds_pad, st, gray, stego, g, qp, bits, bit_offset, n_bits,
-                           n_words, g_guard_counter);
+                           n_words SVS_COUNTER_ARG);
     }
     SVS_HIP(hipGetLastError());
     return SVS_OK;
@@ -321,12 +331,256 @@ int launch_extract_exact(int rows, uint64_t total, hipStream_t st, const uint8_t
     return SVS_OK;
 }
 
-struct DevBuf {  // RAII for the host-pointer entry points
+struct DevBuf {  // RAII (measurement hooks of the experiments library)
     void *p = nullptr;
     ~DevBuf() {
         if (p) (void)hipFree(p);
     }
 };
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Staging context of the HOST-pointer entry points (svs_embed / svs_extract / svs_embed_bgr / svs_extract_bgr).
+// What the reference's per-frame call sites hit (embed_process.py:117-121, extract_process.py:64-68: NumPy arrays in, NumPy
+// arrays out), so it has to run at the rate of the PCIe link, not of hipMalloc:
+//   * one context per HOST THREAD (thread_local): two non-blocking streams, grow-only device buffers, grow-only rings of
+//     pinned staging slots.  Nothing is allocated or freed per call once the buffers have grown to the largest call seen;
+//     svs_shutdown() (or the thread's exit) releases them.  No state carries RESULTS from one call to the next - a call
+//     leaves nothing behind that a later call reads - and two host threads never share a context, so the entry points stay
+//     re-entrant and thread-safe.
+//   * the frames travel in chunks (whole frames, or bands of block rows of a large frame): every upload and kernel goes to
+//     the context's UP stream, in order; every download to its DOWN stream, behind an event recorded after the chunk's
+//     kernel - so chunk k+1's upload runs while chunk k's download does (the link is full duplex).  (Chunks dealt
+//     round-robin to three streams - the first form of this code - fall into lockstep: all three upload together, then
+//     all three download, and the batch moves at the SERIAL rate of the link, 26.6 instead of 40+ Gpixel/s,
+//     profiles/r05_pcie_rate.txt.)  The payload is uploaded once; every chunk indexes it by bit offset.
+//   * a host buffer that is page-locked (svs_host_alloc, hipHostMalloc, hipHostRegister) is the source / target of the DMA
+//     itself; pageable memory goes through the pinned rings (memcpy of slot k+1 beside the DMA of slot k).
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int kStageStreams = 2;      // st[0] = up (H2D copies + kernels), st[1] = down (D2H copies)
+constexpr int kRingSlots = 4;
+constexpr int kChunkEvents = 32;      // "kernel of chunk k done" events, reused round-robin (a stream wait captures the
+                                      // event's record at the time of the call, so re-recording one later is safe)
+#ifndef SVS_STAGE_SLOT_BYTES
+#define SVS_STAGE_SLOT_BYTES (4u << 20)      // bytes per pinned ring slot
+#endif
+#ifndef SVS_STAGE_CHUNK_BYTES
+#define SVS_STAGE_CHUNK_BYTES (4u << 20)     // largest chunk of frames
+#endif
+#ifndef SVS_STAGE_OWN_RING
+#define SVS_STAGE_OWN_RING 1                 // pageable host memory: 1 = through the context's pinned rings, 0 = the runtime's own staging
+#endif
+
+struct Grow {   // grow-only device buffer
+    void *p = nullptr;
+    size_t cap = 0;
+};
+
+struct PendingOut {   // a D2H slot whose bytes still have to be copied to the caller's pageable buffer
+    void *dst = nullptr;
+    size_t bytes = 0;
+};
+
+struct Ring {
+    void *slot[kRingSlots] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t done[kRingSlots] = {nullptr, nullptr, nullptr, nullptr};
+    bool busy[kRingSlots] = {false, false, false, false};
+    PendingOut out[kRingSlots];
+    uint32_t next = 0;
+};
+
+struct HostStage {
+    int device = -1;
+    hipStream_t st[kStageStreams] = {nullptr, nullptr};
+    hipEvent_t chunk_done[kChunkEvents] = {};
+    uint32_t next_event = 0;
+    Grow frames, second, third, bits;   // frames (in place) / BGR in; BGR out; gray reference; payload or extracted bits
+    Ring up, down;
+    ~HostStage() { release(); }
+
+    void release() {
+        if (device < 0) return;
+        int cur = -1;
+        const bool switched = hipGetDevice(&cur) == hipSuccess && cur != device && hipSetDevice(device) == hipSuccess;
+        for (auto &s : st) if (s) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); s = nullptr; }
+        for (auto &e : chunk_done) if (e) { (void)hipEventDestroy(e); e = nullptr; }
+        for (Grow *g : {&frames, &second, &third, &bits}) { if (g->p) (void)hipFree(g->p); g->p = nullptr; g->cap = 0; }
+        for (Ring *r : {&up, &down})
+            for (int k = 0; k < kRingSlots; ++k) {
+                if (r->slot[k]) (void)hipHostFree(r->slot[k]);
+                if (r->done[k]) (void)hipEventDestroy(r->done[k]);
+                r->slot[k] = nullptr; r->done[k] = nullptr; r->busy[k] = false; r->out[k] = PendingOut{};
+            }
+        if (switched) (void)hipSetDevice(cur);
+        (void)hipGetLastError();
+        device = -1;
+    }
+};
+
+thread_local HostStage t_stage;
+
+// the calling thread's context on its current device (created / moved on demand)
+int stage_acquire(HostStage **out) {
+    int dev = 0;
+    SVS_HIP(hipGetDevice(&dev));
+    HostStage &c = t_stage;
+    if (c.device != dev) {
+        c.release();
+        for (auto &s : c.st) SVS_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+        for (auto &e : c.chunk_done) SVS_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        c.device = dev;
+    }
+    *out = &c;
+    return SVS_OK;
+}
+
+int stage_reserve(Grow &g, size_t bytes) {
+    if (bytes <= g.cap) return SVS_OK;
+    if (g.p) { SVS_HIP(hipFree(g.p)); g.p = nullptr; g.cap = 0; }
+    const size_t want = (bytes + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);   // whole 2 MB pages
+    SVS_HIP(hipMalloc(&g.p, want));
+    g.cap = want;
+    return SVS_OK;
+}
+
+int ring_ready(Ring &r) {
+    if (r.slot[0]) return SVS_OK;
+    for (int k = 0; k < kRingSlots; ++k) {
+        SVS_HIP(hipHostMalloc(&r.slot[k], SVS_STAGE_SLOT_BYTES, hipHostMallocDefault));
+        SVS_HIP(hipEventCreateWithFlags(&r.done[k], hipEventDisableTiming));
+    }
+    return SVS_OK;
+}
+
+// is [p, p + bytes) page-locked memory the DMA engines can address?
+bool host_is_pinned(const void *p, size_t bytes) {
+    if (!p || bytes == 0) return false;
+    auto one = [](const void *q) {
+        hipPointerAttribute_t a;
+        if (hipPointerGetAttributes(&a, q) != hipSuccess) { (void)hipGetLastError(); return false; }
+        return a.type == hipMemoryTypeHost;
+    };
+    return one(p) && one(static_cast<const uint8_t *>(p) + bytes - 1);
+}
+
+// host -> device on `st`; returns once the source bytes have been read or belong to a pinned buffer the caller keeps alive
+// until the stream is synchronised
+int stage_h2d(HostStage &c, hipStream_t st, void *d_dst, const void *h_src, size_t bytes, bool pinned) {
+    if (bytes == 0) return SVS_OK;
+    if (pinned || !SVS_STAGE_OWN_RING) {
+        SVS_HIP(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, st));
+        return SVS_OK;
+    }
+    if (int rc = ring_ready(c.up)) return rc;
+    Ring &r = c.up;
+    for (size_t off = 0; off < bytes; off += SVS_STAGE_SLOT_BYTES) {
+        const size_t len = bytes - off < SVS_STAGE_SLOT_BYTES ? bytes - off : (size_t)SVS_STAGE_SLOT_BYTES;
+        const uint32_t k = r.next++ % kRingSlots;
+        if (r.busy[k]) { SVS_HIP(hipEventSynchronize(r.done[k])); r.busy[k] = false; }
+        memcpy(r.slot[k], static_cast<const uint8_t *>(h_src) + off, len);
+        SVS_HIP(hipMemcpyAsync(static_cast<uint8_t *>(d_dst) + off, r.slot[k], len, hipMemcpyHostToDevice, st));
+        SVS_HIP(hipEventRecord(r.done[k], st));
+        r.busy[k] = true;
+    }
+    return SVS_OK;
+}
+
+int ring_retire(Ring &r, uint32_t k) {   // finish slot k of the download ring: wait for its DMA, hand the bytes to the caller
+    if (!r.busy[k]) return SVS_OK;
+    SVS_HIP(hipEventSynchronize(r.done[k]));
+    if (r.out[k].dst) memcpy(r.out[k].dst, r.slot[k], r.out[k].bytes);
+    r.out[k] = PendingOut{};
+    r.busy[k] = false;
+    return SVS_OK;
+}
+
+// device -> host on `st`; pageable targets are complete only after stage_finish()
+int stage_d2h(HostStage &c, hipStream_t st, void *h_dst, const void *d_src, size_t bytes, bool pinned) {
+    if (bytes == 0) return SVS_OK;
+    if (pinned || !SVS_STAGE_OWN_RING) {
+        SVS_HIP(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, st));
+        return SVS_OK;
+    }
+    if (int rc = ring_ready(c.down)) return rc;
+    Ring &r = c.down;
+    for (size_t off = 0; off < bytes; off += SVS_STAGE_SLOT_BYTES) {
+        const size_t len = bytes - off < SVS_STAGE_SLOT_BYTES ? bytes - off : (size_t)SVS_STAGE_SLOT_BYTES;
+        const uint32_t k = r.next++ % kRingSlots;
+        if (int rc = ring_retire(r, k)) return rc;
+        SVS_HIP(hipMemcpyAsync(r.slot[k], static_cast<const uint8_t *>(d_src) + off, len, hipMemcpyDeviceToHost, st));
+        SVS_HIP(hipEventRecord(r.done[k], st));
+        r.out[k] = PendingOut{static_cast<uint8_t *>(h_dst) + off, len};
+        r.busy[k] = true;
+    }
+    return SVS_OK;
+}
+
+// end of a call: every stream drained, every pageable target filled, the rings idle.  Also the error path: a call that fails
+// half way must not leave a DMA in flight into the caller's buffers or a slot marked busy.
+int stage_finish(HostStage &c) {
+    int rc = SVS_OK;
+    for (uint32_t i = 0; i < kRingSlots; ++i) {   // oldest first
+        const uint32_t k = (c.down.next + i) % kRingSlots;
+        if (int e = ring_retire(c.down, k)) rc = rc ? rc : e;
+    }
+    for (auto &s : c.st)
+        if (s && hipStreamSynchronize(s) != hipSuccess) rc = rc ? rc : fail(SVS_ERR_HIP, "hipStreamSynchronize failed: %s", hipGetErrorString(hipGetLastError()));
+    for (int k = 0; k < kRingSlots; ++k) { c.up.busy[k] = false; c.down.busy[k] = false; c.down.out[k] = PendingOut{}; }
+    return rc;
+}
+
+// the DOWN stream may start on what the UP stream has enqueued so far
+int stage_handoff(HostStage &c) {
+    hipEvent_t e = c.chunk_done[c.next_event++ % kChunkEvents];
+    SVS_HIP(hipEventRecord(e, c.st[0]));
+    SVS_HIP(hipStreamWaitEvent(c.st[1], e, 0));
+    return SVS_OK;
+}
+
+struct StageGuard {   // runs stage_finish on every exit path of an entry point
+    HostStage *c;
+    explicit StageGuard(HostStage *ctx) : c(ctx) {}
+    int done(int rc) {
+        const int e = stage_finish(*c);
+        c = nullptr;
+        return rc ? rc : e;
+    }
+    ~StageGuard() { if (c) (void)stage_finish(*c); }
+};
+
+// A chunk of a batch: frames [f0, f0 + nf) x pixel rows [r0, r0 + rows); nf > 1 only with whole frames (r0 = 0, rows = H).
+struct Chunk {
+    int32_t f0, nf, r0, rows;
+};
+
+// Cuts a batch of n_frames frames of H rows (row_bytes bytes of payload per row) into chunks of about `target` bytes: bands of
+// block rows when a frame is larger than that, groups of whole frames otherwise.
+template <class F>
+void for_each_chunk(int32_t n_frames, int32_t H, size_t row_bytes, size_t target, F &&fn) {
+    const size_t frame_bytes = (size_t)H * row_bytes;
+    if (frame_bytes > target && H > 8) {
+        int32_t band = (int32_t)((target / row_bytes) & ~(size_t)7);
+        if (band < 8) band = 8;
+        // equal bands rather than a short last one
+        const int32_t pieces = (H + band - 1) / band;
+        band = (((H / 8) + pieces - 1) / pieces) * 8;
+        for (int32_t f = 0; f < n_frames; ++f)
+            for (int32_t r = 0; r < H; r += band) fn(Chunk{f, 1, r, r + band <= H ? band : H - r});
+    } else {
+        int32_t group = (int32_t)(target / (frame_bytes ? frame_bytes : 1));
+        if (group < 1) group = 1;
+        for (int32_t f = 0; f < n_frames; f += group) fn(Chunk{f, f + group <= n_frames ? group : n_frames - f, 0, H});
+    }
+}
+
+// chunk size of a batch of `total` bytes: an eighth of it, so that a single frame is pipelined as well (one 4K frame = eight
+// bands of 1 MB: nine chunk times instead of sixteen), within [512 KB, 4 MB] - below, the fixed cost of a DMA shows; above,
+// nothing is gained (sweep in profiles/r05_pcie_rate.txt; the experiments library's SVS_STAGE_CHUNK_KB overrides it)
+size_t stage_chunk_bytes(uint64_t total) {
+    const uint32_t forced = knob("SVS_STAGE_CHUNK_KB", 0);
+    if (forced) return (size_t)forced << 10;
+    const uint64_t eighth = total / 8;
+    return (size_t)(eighth < (512u << 10) ? (512u << 10) : (eighth > SVS_STAGE_CHUNK_BYTES ? SVS_STAGE_CHUNK_BYTES : eighth));
+}
 
 template <int QM, bool EXACT>
 int launch_embed_bgr(int rows, uint64_t total, hipStream_t st, const uint8_t *in, uint8_t *out, uint8_t *ref,
@@ -626,49 +880,130 @@ int svs_extract_dev(const uint8_t *d_gray, const svs_planes *planes, double delt
     return SVS_OK;
 }
 
-int svs_embed(const uint8_t *gray, uint8_t *stego, const svs_planes *planes, double delta, int n_ac,
-              const uint8_t *bits_packed, uint64_t bit_offset, uint64_t n_bits, uint32_t flags, uint64_t *n_embedded) {
+// payload window of a host-pointer embed call: only the bytes this call reads go to the device - [first_byte, last_byte),
+// first_byte dword aligned, the bit offset rebased onto it (a frame loop that indexes one long stream by bit_offset stays
+// O(batch) per call).  Uploaded on the UP stream, ahead of the kernels that read it.
+static int stage_payload(HostStage &c, const uint8_t *bits_packed, uint64_t bit_offset, uint64_t use, uint64_t *rebased) {
+    const uint64_t first_byte = use ? (bit_offset / 32) * 4 : 0;
+    const uint64_t bit_bytes = use ? (bit_offset + use + 7) / 8 - first_byte : 0;
+    const uint64_t bit_alloc = ((bit_bytes + 3) / 4) * 4 + 4;
+    if (int rc = stage_reserve(c.bits, bit_alloc)) return rc;
+    if (bit_bytes) {
+        // the kernels read whole dwords: the tail behind the last payload byte must be defined (zero)
+        SVS_HIP(hipMemsetAsync(static_cast<uint8_t *>(c.bits.p) + (bit_alloc - 8), 0, 8, c.st[0]));
+        if (int rc = stage_h2d(c, c.st[0], c.bits.p, bits_packed + first_byte, bit_bytes, host_is_pinned(bits_packed + first_byte, bit_bytes)))
+            return rc;
+    } else {
+        SVS_HIP(hipMemsetAsync(c.bits.p, 0, bit_alloc, c.st[0]));
+    }
+    *rebased = bit_offset - 8 * first_byte;
+    return SVS_OK;
+}
+
+// the same for a payload of `use` '0' / '1' characters: uploaded as they are (one byte per bit) and packed on the device
+static int stage_payload_ascii(HostStage &c, const char *bits_ascii, uint64_t use) {
+    const uint64_t words = (use + 31) / 32, bit_alloc = 4 * words + 8;
+    if (int rc = stage_reserve(c.bits, bit_alloc)) return rc;
+    SVS_HIP(hipMemsetAsync(static_cast<uint8_t *>(c.bits.p) + 4 * words, 0, 8, c.st[0]));
+    if (use == 0) return SVS_OK;
+    if (int rc = stage_reserve(c.third, use + 32)) return rc;
+    if (int rc = stage_h2d(c, c.st[0], c.third.p, bits_ascii, use, host_is_pinned(bits_ascii, use))) return rc;
+    const uint32_t blocks = (uint32_t)((words + 255) / 256 < 2048 ? (words + 255) / 256 : 2048);
+    hipLaunchKernelGGL(svs::ascii_to_packed_kernel, dim3(blocks), dim3(256), 0, c.st[0], static_cast<const uint8_t *>(c.third.p), use,
+                       static_cast<uint32_t *>(c.bits.p), words);
+    SVS_HIP(hipGetLastError());
+    return SVS_OK;
+}
+
+// bits a chunk that starts at global block g0 sees of a budget of `pass_bits` bits (pass_bits = 1 with nothing embeddable:
+// "non-empty payload", every block is round-tripped - for every chunk alike)
+static uint64_t chunk_budget(uint64_t pass_bits, uint64_t use, uint64_t g0, uint32_t n) {
+    if (use == 0) return pass_bits;
+    const uint64_t before = g0 * (uint64_t)n;
+    return pass_bits > before ? pass_bits - before : 0;
+}
+
+// svs_embed (payload = packed MSB-first bits, indexed by bit_offset) and svs_embed_str (payload = n_bits '0' / '1' characters,
+// bit_offset = 0) share everything but the way the payload reaches the device
+static int embed_host(const uint8_t *gray, uint8_t *stego, const svs_planes *planes, double delta, int n_ac,
+                      const uint8_t *bits_packed, const char *bits_ascii, uint64_t bit_offset, uint64_t n_bits, uint32_t flags,
+                      uint64_t *n_embedded) {
     svs::Geometry g;
     uint64_t total = 0;
     if (int rc = make_geometry(planes, n_ac, &g, &total)) return rc;
     if (n_embedded) *n_embedded = 0;
     if (total == 0) return SVS_OK;
     if (!gray || !stego) return fail(SVS_ERR_INVALID_ARG, "gray/stego pointer is NULL");
+    if (flags & ~(SVS_EXACT_POCKETFFT | SVS_EXACT_GUARDED)) return fail(SVS_ERR_INVALID_ARG, "unknown flags 0x%x", flags);
     const uint64_t span = span_bytes(planes);
     const uint64_t cap = total * (uint64_t)g.n_ac;
-    const uint64_t use = n_bits < cap ? n_bits : cap;
-    if (use && !bits_packed) return fail(SVS_ERR_INVALID_ARG, "bits pointer is NULL");
-    // only the payload bytes this call reads go to the device: [first_byte, last_byte), first_byte dword aligned, the
-    // bit offset rebased onto it (a frame loop that indexes one long stream by bit_offset stays O(batch) per call)
-    const uint64_t first_byte = use ? (bit_offset / 32) * 4 : 0;
-    const uint64_t bit_bytes = use ? (bit_offset + use + 7) / 8 - first_byte : 0;
-    const uint64_t bit_alloc = ((bit_bytes + 3) / 4) * 4 + 4;
-    DevBuf d_frames, d_bits;
-    SVS_HIP(hipMalloc(&d_frames.p, span));
-    SVS_HIP(hipMalloc(&d_bits.p, bit_alloc));
-    SVS_HIP(hipMemcpy(d_frames.p, gray, span, hipMemcpyHostToDevice));
-    SVS_HIP(hipMemset(d_bits.p, 0, bit_alloc));
-    if (bit_bytes) SVS_HIP(hipMemcpy(d_bits.p, bits_packed + first_byte, bit_bytes, hipMemcpyHostToDevice));
-    uint64_t done = 0;
-    // a non-empty payload that cannot be embedded (delta <= 0, n_ac = 0) must still reach the kernel as
-    // "non-empty": every block is then round-tripped, as in the reference
-    const uint64_t pass_bits = use ? use : (n_bits ? 1 : 0);
-    if (int rc = svs_embed_dev((const uint8_t *)d_frames.p, (uint8_t *)d_frames.p, planes, delta, n_ac,
-                               (const uint8_t *)d_bits.p, bit_offset - 8 * first_byte, pass_bits, flags, &done, nullptr))
-        return rc;
-    // copy back pixel bytes only (padding in the caller's stego buffer is left alone)
-    if (planes->row_pitch == planes->width && planes->frame_pitch == (int64_t)planes->height * planes->row_pitch) {
-        SVS_HIP(hipMemcpy(stego, d_frames.p, span, hipMemcpyDeviceToHost));
-    } else {
-        for (int f = 0; f < planes->n_frames; ++f)
-            SVS_HIP(hipMemcpy2D(stego + (int64_t)f * planes->frame_pitch, (size_t)planes->row_pitch,
-                                (const uint8_t *)d_frames.p + (int64_t)f * planes->frame_pitch,
-                                (size_t)planes->row_pitch, (size_t)planes->width, (size_t)planes->height,
-                                hipMemcpyDeviceToHost));
+    uint64_t use = n_bits < cap ? n_bits : cap;
+    if (!(delta > 0.0)) use = 0;                   // nothing can be embedded (config_and_setup.py:143-145)
+    if (use && !bits_packed && !bits_ascii) return fail(SVS_ERR_INVALID_ARG, "bits pointer is NULL");
+    if (use && bit_offset + use < bit_offset) return fail(SVS_ERR_INVALID_ARG, "bit_offset + n_bits overflows");
+    HostStage *ctx = nullptr;
+    if (int rc = stage_acquire(&ctx)) return rc;
+    HostStage &c = *ctx;
+    StageGuard guard(ctx);
+    if (int rc = stage_reserve(c.frames, span)) return guard.done(rc);
+    uint64_t rebased = 0;
+    if (bits_ascii) {
+        if (int rc = stage_payload_ascii(c, bits_ascii, use)) return guard.done(rc);
+    } else if (int rc = stage_payload(c, bits_packed, bit_offset, use, &rebased)) {
+        return guard.done(rc);
     }
-    SVS_HIP(hipDeviceSynchronize());
-    if (n_embedded) *n_embedded = done;
+    // a non-empty payload that cannot be embedded (delta <= 0, n_ac = 0) must still reach the kernel as "non-empty": every
+    // block is then round-tripped, as in the reference
+    const uint64_t pass_bits = use ? use : (n_bits ? 1 : 0);
+    const bool in_pinned = host_is_pinned(gray, span), out_pinned = host_is_pinned(stego, span);
+    const int32_t H = planes->height, W = planes->width;
+    const int64_t rp = planes->row_pitch, fp = planes->frame_pitch;
+    const bool rows_packed = rp == W, frames_packed = rows_packed && fp == (int64_t)H * W;
+    const uint64_t wb = (uint64_t)W / 8, bpf = wb * ((uint64_t)H / 8);
+    uint8_t *d = static_cast<uint8_t *>(c.frames.p);
+    uint64_t done_total = 0;
+    int rc = SVS_OK;
+    hipStream_t up = c.st[0], st = c.st[1];
+    for_each_chunk(planes->n_frames, H, (size_t)rp, stage_chunk_bytes(span), [&](const Chunk &ch) {
+        if (rc) return;
+        const int64_t off = (int64_t)ch.f0 * fp + (int64_t)ch.r0 * rp;
+        const size_t bytes = ch.nf == 1 ? (size_t)(ch.rows - 1) * rp + W : (size_t)(ch.nf - 1) * fp + (size_t)(H - 1) * rp + W;
+        if ((rc = stage_h2d(c, up, d + off, gray + off, bytes, in_pinned))) return;
+        const svs_planes sub{ch.nf, ch.rows, W, 0, rp, ch.nf == 1 ? (int64_t)ch.rows * rp : fp};
+        const uint64_t g0 = (uint64_t)ch.f0 * bpf + (uint64_t)(ch.r0 / 8) * wb;
+        uint64_t done = 0;
+        if ((rc = svs_embed_dev(d + off, d + off, &sub, delta, n_ac, static_cast<const uint8_t *>(c.bits.p),
+                                rebased + (use ? g0 * (uint64_t)g.n_ac : 0), chunk_budget(pass_bits, use, g0, g.n_ac), flags, &done, up)))
+            return;
+        done_total += done;
+        if ((rc = stage_handoff(c))) return;
+        // back: pixel bytes only (padding in the caller's stego buffer is left alone)
+        if (frames_packed || (rows_packed && ch.nf == 1)) {
+            rc = stage_d2h(c, st, stego + off, d + off, ch.nf == 1 ? (size_t)ch.rows * W : (size_t)ch.nf * H * W, out_pinned);
+        } else {
+            for (int32_t f = 0; f < ch.nf && !rc; ++f) {
+                const int64_t o = off + (int64_t)f * fp;
+                if (rows_packed) rc = stage_d2h(c, st, stego + o, d + o, (size_t)ch.rows * W, out_pinned);
+                else if (hipMemcpy2DAsync(stego + o, (size_t)rp, d + o, (size_t)rp, (size_t)W, (size_t)ch.rows, hipMemcpyDeviceToHost, st) != hipSuccess)
+                    rc = fail(SVS_ERR_HIP, "hipMemcpy2DAsync failed: %s", hipGetErrorString(hipGetLastError()));
+            }
+        }
+    });
+    rc = guard.done(rc);
+    if (rc) return rc;
+    if (n_embedded) *n_embedded = done_total;
     return SVS_OK;
+}
+
+int svs_embed(const uint8_t *gray, uint8_t *stego, const svs_planes *planes, double delta, int n_ac,
+              const uint8_t *bits_packed, uint64_t bit_offset, uint64_t n_bits, uint32_t flags, uint64_t *n_embedded) {
+    return embed_host(gray, stego, planes, delta, n_ac, bits_packed, nullptr, bit_offset, n_bits, flags, n_embedded);
+}
+
+int svs_embed_str(const uint8_t *gray, uint8_t *stego, const svs_planes *planes, double delta, int n_ac,
+                  const char *bits_ascii, uint64_t n_chars, uint32_t flags, uint64_t *n_embedded) {
+    if (n_chars && !bits_ascii) return fail(SVS_ERR_INVALID_ARG, "bits pointer is NULL");
+    return embed_host(gray, stego, planes, delta, n_ac, nullptr, bits_ascii ? bits_ascii : "", 0, n_chars, flags, n_embedded);
 }
 
 int svs_extract(const uint8_t *gray, const svs_planes *planes, double delta, int n_ac, uint8_t *bits_packed_out,
@@ -685,17 +1020,64 @@ int svs_extract(const uint8_t *gray, const svs_planes *planes, double delta, int
         return fail(SVS_ERR_CAPACITY, "extract needs %llu bytes, buffer has %llu", (unsigned long long)bytes,
                     (unsigned long long)out_capacity_bytes);
     const uint64_t span = span_bytes(planes);
-    DevBuf d_frames, d_bits;
-    SVS_HIP(hipMalloc(&d_frames.p, span));
-    SVS_HIP(hipMalloc(&d_bits.p, bytes + 8));
-    SVS_HIP(hipMemcpy(d_frames.p, gray, span, hipMemcpyHostToDevice));
+    HostStage *ctx = nullptr;
+    if (int rc = stage_acquire(&ctx)) return rc;
+    HostStage &c = *ctx;
+    StageGuard guard(ctx);
+    if (int rc = stage_reserve(c.frames, span)) return guard.done(rc);
+    if (int rc = stage_reserve(c.bits, bytes + 8)) return guard.done(rc);
+    // the download is n_ac / 512 of the upload: one stream, one kernel over the batch; the upload is chunked only through
+    // the pinned ring when the caller's frames are pageable
+    hipStream_t st = c.st[0];
+    if (int rc = stage_h2d(c, st, c.frames.p, gray, span, host_is_pinned(gray, span))) return guard.done(rc);
     uint64_t got = 0;
-    if (int rc = svs_extract_dev((const uint8_t *)d_frames.p, planes, delta, n_ac, (uint8_t *)d_bits.p, bytes + 8, flags,
-                                 &got, nullptr))
-        return rc;
-    SVS_HIP(hipMemcpy(bits_packed_out, d_bits.p, bytes, hipMemcpyDeviceToHost));
-    SVS_HIP(hipDeviceSynchronize());
+    if (int rc = svs_extract_dev(static_cast<const uint8_t *>(c.frames.p), planes, delta, n_ac, static_cast<uint8_t *>(c.bits.p),
+                                 bytes + 8, flags, &got, st))
+        return guard.done(rc);
+    if (int rc = stage_d2h(c, st, bits_packed_out, c.bits.p, bytes, host_is_pinned(bits_packed_out, bytes))) return guard.done(rc);
+    if (int rc = guard.done(SVS_OK)) return rc;
     if (n_bits_out) *n_bits_out = got;
+    return SVS_OK;
+}
+
+int svs_extract_str(const uint8_t *gray, const svs_planes *planes, double delta, int n_ac, char *bits_ascii_out,
+                    uint64_t out_capacity_chars, uint32_t flags, uint64_t *n_bits_out) {
+    svs::Geometry g;
+    uint64_t total = 0;
+    if (int rc = make_geometry(planes, n_ac, &g, &total)) return rc;
+    if (n_bits_out) *n_bits_out = 0;
+    const uint64_t cap = total * (uint64_t)g.n_ac;
+    if (cap == 0) return SVS_OK;
+    if (!gray || !bits_ascii_out) return fail(SVS_ERR_INVALID_ARG, "gray/bits pointer is NULL");
+    if (out_capacity_chars < cap)
+        return fail(SVS_ERR_CAPACITY, "extract needs %llu characters, buffer has %llu", (unsigned long long)cap,
+                    (unsigned long long)out_capacity_chars);
+    const uint64_t bytes = (cap + 7) / 8, span = span_bytes(planes);
+    HostStage *ctx = nullptr;
+    if (int rc = stage_acquire(&ctx)) return rc;
+    HostStage &c = *ctx;
+    StageGuard guard(ctx);
+    if (int rc = stage_reserve(c.frames, span)) return guard.done(rc);
+    if (int rc = stage_reserve(c.bits, bytes + 8)) return guard.done(rc);
+    if (int rc = stage_reserve(c.third, 8 * bytes + 8)) return guard.done(rc);
+    hipStream_t st = c.st[0];
+    if (int rc = stage_h2d(c, st, c.frames.p, gray, span, host_is_pinned(gray, span))) return guard.done(rc);
+    uint64_t got = 0;
+    if (int rc = svs_extract_dev(static_cast<const uint8_t *>(c.frames.p), planes, delta, n_ac, static_cast<uint8_t *>(c.bits.p),
+                                 bytes + 8, flags, &got, st))
+        return guard.done(rc);
+    const uint32_t blocks = (uint32_t)((bytes + 255) / 256 < 4096 ? (bytes + 255) / 256 : 4096);
+    hipLaunchKernelGGL(svs::packed_to_ascii_kernel, dim3(blocks), dim3(256), 0, st, static_cast<const uint8_t *>(c.bits.p), bytes,
+                       static_cast<svs::u32x2 *>(c.third.p));
+    if (hipGetLastError() != hipSuccess) return guard.done(fail(SVS_ERR_HIP, "packed_to_ascii_kernel launch failed"));
+    if (int rc = stage_d2h(c, st, bits_ascii_out, c.third.p, cap, host_is_pinned(bits_ascii_out, cap))) return guard.done(rc);
+    if (int rc = guard.done(SVS_OK)) return rc;
+    if (n_bits_out) *n_bits_out = got;
+    return SVS_OK;
+}
+
+int svs_shutdown(void) {
+    t_stage.release();
     return SVS_OK;
 }
 
@@ -890,32 +1272,53 @@ int svs_embed_bgr(const uint8_t *bgr, uint8_t *bgr_out, uint8_t *gray_ref_out, c
     if (total == 0) return SVS_OK;
     if (int rc = packed_planes_only(planes)) return rc;
     if (!bgr || !bgr_out) return fail(SVS_ERR_INVALID_ARG, "BGR pointer is NULL");
-    const uint64_t px = (uint64_t)planes->n_frames * planes->height * planes->width;
+    if (flags & ~(SVS_EXACT_POCKETFFT | SVS_EXACT_GUARDED)) return fail(SVS_ERR_INVALID_ARG, "unknown flags 0x%x", flags);
+    const int32_t H = planes->height, W = planes->width;
+    const uint64_t px = (uint64_t)planes->n_frames * H * W;
     const uint64_t cap = total * (uint64_t)g.n_ac;
-    const uint64_t use = n_bits < cap ? n_bits : cap;
+    uint64_t use = n_bits < cap ? n_bits : cap;
+    if (!(delta > 0.0)) use = 0;
     if (use && !bits_packed) return fail(SVS_ERR_INVALID_ARG, "bits pointer is NULL");
-    const uint64_t first_byte = use ? (bit_offset / 32) * 4 : 0;     // see svs_embed
-    const uint64_t bit_bytes = use ? (bit_offset + use + 7) / 8 - first_byte : 0;
-    const uint64_t bit_alloc = ((bit_bytes + 3) / 4) * 4 + 4;
-    DevBuf d_in, d_out, d_gray, d_bits;
-    SVS_HIP(hipMalloc(&d_in.p, 3 * px));
-    SVS_HIP(hipMalloc(&d_out.p, 3 * px));
-    if (gray_ref_out) SVS_HIP(hipMalloc(&d_gray.p, px));
-    SVS_HIP(hipMalloc(&d_bits.p, bit_alloc));
-    SVS_HIP(hipMemcpy(d_in.p, bgr, 3 * px, hipMemcpyHostToDevice));
-    SVS_HIP(hipMemset(d_bits.p, 0, bit_alloc));
-    if (bit_bytes) SVS_HIP(hipMemcpy(d_bits.p, bits_packed + first_byte, bit_bytes, hipMemcpyHostToDevice));
-    const int64_t rp = 3 * (int64_t)planes->width, fp = rp * planes->height;
-    uint64_t done = 0;
-    const uint64_t pass_bits = use ? use : (n_bits ? 1 : 0);  // see svs_embed
-    if (int rc = svs_embed_bgr_dev((const uint8_t *)d_in.p, rp, fp, (uint8_t *)d_out.p, rp, fp, (uint8_t *)d_gray.p, planes,
-                                   weights, delta, n_ac, (const uint8_t *)d_bits.p, bit_offset - 8 * first_byte, pass_bits,
-                                   flags, &done, nullptr))
-        return rc;
-    SVS_HIP(hipMemcpy(bgr_out, d_out.p, 3 * px, hipMemcpyDeviceToHost));
-    if (gray_ref_out) SVS_HIP(hipMemcpy(gray_ref_out, d_gray.p, px, hipMemcpyDeviceToHost));
-    SVS_HIP(hipDeviceSynchronize());
-    if (n_embedded) *n_embedded = done;
+    if (use && bit_offset + use < bit_offset) return fail(SVS_ERR_INVALID_ARG, "bit_offset + n_bits overflows");
+    HostStage *ctx = nullptr;
+    if (int rc = stage_acquire(&ctx)) return rc;
+    HostStage &c = *ctx;
+    StageGuard guard(ctx);
+    if (int rc = stage_reserve(c.frames, 3 * px)) return guard.done(rc);
+    if (int rc = stage_reserve(c.second, 3 * px)) return guard.done(rc);
+    if (gray_ref_out)
+        if (int rc = stage_reserve(c.third, px)) return guard.done(rc);
+    uint64_t rebased = 0;
+    if (int rc = stage_payload(c, bits_packed, bit_offset, use, &rebased)) return guard.done(rc);
+    const uint64_t pass_bits = use ? use : (n_bits ? 1 : 0);   // see svs_embed
+    const bool in_pinned = host_is_pinned(bgr, 3 * px), out_pinned = host_is_pinned(bgr_out, 3 * px),
+               ref_pinned = gray_ref_out && host_is_pinned(gray_ref_out, px);
+    const uint64_t wb = (uint64_t)W / 8, bpf = wb * ((uint64_t)H / 8);
+    const int64_t rp3 = 3 * (int64_t)W;
+    uint8_t *d_in = static_cast<uint8_t *>(c.frames.p), *d_out = static_cast<uint8_t *>(c.second.p),
+            *d_ref = gray_ref_out ? static_cast<uint8_t *>(c.third.p) : nullptr;
+    uint64_t done_total = 0;
+    int rc = SVS_OK;
+    hipStream_t up = c.st[0], st = c.st[1];
+    for_each_chunk(planes->n_frames, H, (size_t)rp3, stage_chunk_bytes(3 * px), [&](const Chunk &ch) {   // frames are tightly packed: every chunk is one run of bytes
+        if (rc) return;
+        const uint64_t first_px = ((uint64_t)ch.f0 * H + ch.r0) * W, n_px = (uint64_t)ch.nf * ch.rows * W;
+        if ((rc = stage_h2d(c, up, d_in + 3 * first_px, bgr + 3 * first_px, 3 * n_px, in_pinned))) return;
+        const svs_planes sub{ch.nf, ch.rows, W, 0, W, (int64_t)ch.rows * W};
+        const uint64_t g0 = (uint64_t)ch.f0 * bpf + (uint64_t)(ch.r0 / 8) * wb;
+        uint64_t done = 0;
+        if ((rc = svs_embed_bgr_dev(d_in + 3 * first_px, rp3, rp3 * ch.rows, d_out + 3 * first_px, rp3, rp3 * ch.rows,
+                                    d_ref ? d_ref + first_px : nullptr, &sub, weights, delta, n_ac, static_cast<const uint8_t *>(c.bits.p),
+                                    rebased + (use ? g0 * (uint64_t)g.n_ac : 0), chunk_budget(pass_bits, use, g0, g.n_ac), flags, &done, up)))
+            return;
+        done_total += done;
+        if ((rc = stage_handoff(c))) return;
+        if ((rc = stage_d2h(c, st, bgr_out + 3 * first_px, d_out + 3 * first_px, 3 * n_px, out_pinned))) return;
+        if (d_ref) rc = stage_d2h(c, st, gray_ref_out + first_px, d_ref + first_px, n_px, ref_pinned);
+    });
+    rc = guard.done(rc);
+    if (rc) return rc;
+    if (n_embedded) *n_embedded = done_total;
     return SVS_OK;
 }
 
@@ -934,17 +1337,21 @@ int svs_extract_bgr(const uint8_t *bgr, const svs_planes *planes, const uint32_t
         return fail(SVS_ERR_CAPACITY, "extract needs %llu bytes, buffer has %llu", (unsigned long long)bytes,
                     (unsigned long long)out_capacity_bytes);
     const uint64_t px = (uint64_t)planes->n_frames * planes->height * planes->width;
-    DevBuf d_in, d_bits;
-    SVS_HIP(hipMalloc(&d_in.p, 3 * px));
-    SVS_HIP(hipMalloc(&d_bits.p, bytes + 8));
-    SVS_HIP(hipMemcpy(d_in.p, bgr, 3 * px, hipMemcpyHostToDevice));
+    HostStage *ctx = nullptr;
+    if (int rc = stage_acquire(&ctx)) return rc;
+    HostStage &c = *ctx;
+    StageGuard guard(ctx);
+    if (int rc = stage_reserve(c.frames, 3 * px)) return guard.done(rc);
+    if (int rc = stage_reserve(c.bits, bytes + 8)) return guard.done(rc);
+    hipStream_t st = c.st[0];
+    if (int rc = stage_h2d(c, st, c.frames.p, bgr, 3 * px, host_is_pinned(bgr, 3 * px))) return guard.done(rc);
     const int64_t rp = 3 * (int64_t)planes->width, fp = rp * planes->height;
     uint64_t got = 0;
-    if (int rc = svs_extract_bgr_dev((const uint8_t *)d_in.p, rp, fp, planes, weights, delta, n_ac, (uint8_t *)d_bits.p,
-                                     bytes + 8, &got, nullptr))
-        return rc;
-    SVS_HIP(hipMemcpy(bits_packed_out, d_bits.p, bytes, hipMemcpyDeviceToHost));
-    SVS_HIP(hipDeviceSynchronize());
+    if (int rc = svs_extract_bgr_dev(static_cast<const uint8_t *>(c.frames.p), rp, fp, planes, weights, delta, n_ac,
+                                     static_cast<uint8_t *>(c.bits.p), bytes + 8, &got, st))
+        return guard.done(rc);
+    if (int rc = stage_d2h(c, st, bits_packed_out, c.bits.p, bytes, host_is_pinned(bits_packed_out, bytes))) return guard.done(rc);
+    if (int rc = guard.done(SVS_OK)) return rc;
     if (n_bits_out) *n_bits_out = got;
     return SVS_OK;
 }
@@ -1051,8 +1458,11 @@ int svs_bit_errors_dev(const uint8_t *d_a_packed, const uint8_t *d_b_packed, uin
     return SVS_OK;
 }
 
-// measurement hook (not part of the product ABI): device counter (uint64, caller-zeroed) that guarded embed launches add
-// the number of blocks they redid with the exact arithmetic to; NULL switches it off
+#if defined(SVS_EXPERIMENTS)
+// ---- measurement hooks: lib/variants/libsvsdct_exp.so ONLY (the product library exports exactly what include/svsdct.h declares,
+// tests/test_capi_cpu.py::test_library_exports_exactly_the_declared_symbols) ----
+// device counter (uint64, caller-zeroed) that guarded embed launches add the number of blocks they redid with the exact
+// arithmetic to; NULL switches it off.  Process-global: single-threaded measurement use only.
 int svs_guard_counter_set(void *d_counter) {
     g_guard_counter = reinterpret_cast<unsigned long long *>(d_counter);
     return SVS_OK;
@@ -1111,5 +1521,6 @@ int svs_probe_cvt_pk_u8(const float *host_in, uint32_t *host_out, int n) {
     SVS_HIP(hipMemcpy(host_out, b.p, sizeof(uint32_t) * n, hipMemcpyDeviceToHost));
     return SVS_OK;
 }
+#endif  // SVS_EXPERIMENTS
 
 }  // extern "C"

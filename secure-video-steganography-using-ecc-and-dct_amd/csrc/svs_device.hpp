@@ -761,12 +761,18 @@ constexpr int kEmbedMinWaves = U == 2 ? SVS_U2_MIN_WAVES : 1;
 #ifndef SVS_U2_INPLACE
 #define SVS_U2_INPLACE 1
 #endif
+// The experiments library (-DSVS_EXPERIMENTS) counts the blocks a launch redid exactly into a device counter (measurement
+// hook svs_guard_counter_set); the product kernels have no such parameter and the product library no such state.
+#if defined(SVS_EXPERIMENTS)
+#define SVS_REPLAY_COUNTER_PARAM , unsigned long long *__restrict__ replay_counter
+#else
+#define SVS_REPLAY_COUNTER_PARAM
+#endif
 template <int U, int QM, int BPL, int NFIX = 0>   // NFIX: compile-time n (two rows only; svs_capi.hip instantiates the GUI's default 10)
 __global__ __launch_bounds__(SVS_WG, kEmbedMinWaves<U>) void embed_kernel(const uint8_t *gray,
                                                     uint8_t *stego, const Geometry g, const QimParams qp,
                                                     const uint32_t *__restrict__ bits, const uint64_t bit_offset,
-                                                    const uint64_t n_bits, const uint32_t n_words,
-                                                    unsigned long long *__restrict__ replay_counter) {
+                                                    const uint64_t n_bits, const uint32_t n_words SVS_REPLAY_COUNTER_PARAM) {
     static_assert(U <= 2, "n <= 15 (svs_capi.hip: more coefficient rows run embed_exact_kernel in every mode)");
     static_assert(NFIX == 0 || U == 2, "compile-time n: two coefficient rows only");
     constexpr bool WGPOOL = U == 2 && BPL == 1 && SVS_U2_WGPOOL;
@@ -846,7 +852,11 @@ __global__ __launch_bounds__(SVS_WG, kEmbedMinWaves<U>) void embed_kernel(const 
         redone = guard_phase2<QM, BPL == 2, CAP, KEPT>(&entries[wave][0], &tiles[wave][0], lane, n, qp, pl, und_a, first_a, ax, ay,
                                                        und_b, first_a + n, bx, by, hi_a, hi_b);
     }
+#if defined(SVS_EXPERIMENTS)
     if (replay_counter != nullptr && redone != 0 && lane == 0) atomicAdd(replay_counter, (unsigned long long)redone);
+#else
+    (void)redone;
+#endif
     if (write) {
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
@@ -930,6 +940,44 @@ __global__ __launch_bounds__(256) void fill_bits_kernel(uint32_t *__restrict__ w
             if (i < n_bits) be |= (lowbias32(s + (uint32_t)(first_bit + i)) >> 31) << (31 - j);
         }
         words[w] = __builtin_bswap32(be);
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// The reference operator's payload types are Python strings of '0' / '1' characters (bit_payload_segment in, the joined
+// string out: config_and_setup.py:106-109,124-126,173-174).  The host-pointer entry points svs_embed_str / svs_extract_str
+// take / return exactly that; the conversion to and from the packed stream runs here, on the device, at the price of moving
+// one byte per bit over the link (1.3 MB for a 4K frame at n = 10: 25 us) instead of three host passes over it.
+// 32 characters -> one packed dword: the bit is the low bit of the character ('0' = 0x30, '1' = 0x31); four of them times
+// 0x08040201 leave the nibble c0 c1 c2 c3 in bits 27..24 of the product (no carries: every cross term lands below bit 19).
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ascii_to_packed_kernel(const uint8_t *__restrict__ ascii, uint64_t n_chars,
+                                                              uint32_t *__restrict__ words, uint64_t n_words) {
+    for (uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; w < n_words; w += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t base = 32ull * w;
+        uint32_t d[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (base + 32 <= n_chars) {
+            const u32x4 a = *reinterpret_cast<const u32x4 *>(ascii + base), b = *reinterpret_cast<const u32x4 *>(ascii + base + 16);
+            d[0] = a.x; d[1] = a.y; d[2] = a.z; d[3] = a.w; d[4] = b.x; d[5] = b.y; d[6] = b.z; d[7] = b.w;
+        } else {
+            for (uint32_t j = 0; j < 32 && base + j < n_chars; ++j) d[j >> 2] |= (uint32_t)ascii[base + j] << (8 * (j & 3));
+        }
+        uint32_t be = 0;   // stream bit 32 w + j at bit 31 - j
+#pragma unroll
+        for (int j = 0; j < 8; ++j) be |= ((((d[j] & 0x01010101u) * 0x08040201u) >> 24) & 0xfu) << (28 - 4 * j);
+        words[w] = __builtin_bswap32(be);
+    }
+}
+
+// one packed byte -> its eight characters, MSB first
+__global__ __launch_bounds__(256) void packed_to_ascii_kernel(const uint8_t *__restrict__ packed, uint64_t n_bytes,
+                                                              u32x2 *__restrict__ ascii8) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_bytes; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t v = packed[i];
+        u32x2 o;
+        o.x = 0x30303030u | ((v >> 7) & 1u) | (((v >> 6) & 1u) << 8) | (((v >> 5) & 1u) << 16) | (((v >> 4) & 1u) << 24);
+        o.y = 0x30303030u | ((v >> 3) & 1u) | (((v >> 2) & 1u) << 8) | (((v >> 1) & 1u) << 16) | ((v & 1u) << 24);
+        ascii8[i] = o;
     }
 }
 
@@ -1426,6 +1474,7 @@ __global__ void frame_range_finish_kernel(const uint32_t *__restrict__ lohi, int
     if (f < n_frames) range[f] = (double)lohi[2 * f + 1] - (double)lohi[2 * f];
 }
 
+#if defined(SVS_EXPERIMENTS)   // measurement kernels behind the experiments library's svs_ref_* / svs_probe_* hooks
 // 8-byte-per-lane copy (what the one-block-per-lane kernels issue): non-temporal load, write-through or non-temporal store
 template <int SC1>
 __global__ __launch_bounds__(256) void copy8_kernel(const u32x2 *__restrict__ src, u32x2 *__restrict__ dst, uint64_t n8) {
@@ -1520,5 +1569,6 @@ __global__ void probe_cvt_pk_u8_kernel(const float *__restrict__ in, uint32_t *_
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = __builtin_amdgcn_cvt_pk_u8_f32(in[i], 0, 0u);
 }
+#endif  // SVS_EXPERIMENTS
 
 }  // namespace svs

@@ -18,40 +18,45 @@ import os
 import numpy as np
 
 from . import native
+from .hostmem import pinned_empty
 from .native import Planes
 
 MAX_AC = 63
 
-# Transform mode (include/svsdct.h `flags`).  Every mode produces the reference's stego pixels and bits (round 4); the modes
-# only differ in which kernels get there:
+# Transform mode (include/svsdct.h `flags`).  Every mode produces the reference's stego pixels and bits; the modes only
+# differ in which kernels get there:
 #   "guarded" n_ac <= 15 and 0.25 <= delta <= 4096: the streaming kernel (cheap sparse transform wherever a rigorous bound
 #            on the reference's float32 round-trip noise proves it equals the reference's truncation, the pocketfft-identical
 #            arithmetic inside the same launch for the blocks where it cannot; 8 tests per block at n_ac <= 7, 64 at
 #            n_ac = 8..15); otherwise the "exact" kernels.  Extraction: n_ac <= 7 the pocketfft-identical forward, n_ac >= 8 the
-#            FMA-factored forward with a proven per-block tie margin (the reference's bits for any input).  The default.
-#   "fast"   flags = 0 of the C ABI: the same launches as "guarded" (rounds 1-3 had a separate contract-level embed
-#            arithmetic for n_ac >= 8 here; it is gone, see csrc/svs_block.hpp).
+#            FMA-factored forward with a proven per-block tie margin (the reference's bits for any input).
+#   "fast"   flags = 0 of the C ABI: the same launches as "guarded" (kept for ABI compatibility).
 #   "exact"  pocketfft-identical arithmetic on every block, one lane per block - the yardstick (VALU-bound).
-# SVS_DCT_MODE=fast|exact|guarded overrides the defaults.
+# DEFAULT_MODE is THE product default: every entry point of this module, FramePipeline, the drop-in operator, both drop-in
+# video loops and bench.py resolve an unspecified mode through resolve_mode() - nothing else chooses one
+# (tests/test_capi_cpu.py::test_one_default_mode_everywhere).  The Python layer (not the shared library) lets
+# SVS_DCT_MODE=fast|exact|guarded override it for a whole process.
+DEFAULT_MODE = "guarded"
+_MODE_FLAGS = {"fast": 0, "exact": native.SVS_EXACT_POCKETFFT, "guarded": native.SVS_EXACT_GUARDED}
 _ENV_MODE = os.environ.get("SVS_DCT_MODE")
 
 
-def mode_flags(mode, default: str) -> int:
-    mode = mode or _ENV_MODE or default
-    if mode == "fast":
-        return 0
-    if mode == "exact":
-        return native.SVS_EXACT_POCKETFFT
-    if mode == "guarded":
-        return native.SVS_EXACT_GUARDED
-    raise ValueError(f"unknown transform mode {mode!r} (use 'fast', 'exact' or 'guarded')")
+def resolve_mode(mode: str | None = None) -> str:
+    """explicit argument > SVS_DCT_MODE > DEFAULT_MODE"""
+    mode = mode or _ENV_MODE or DEFAULT_MODE
+    if mode not in _MODE_FLAGS:
+        raise ValueError(f"unknown transform mode {mode!r} (use 'fast', 'exact' or 'guarded')")
+    return mode
+
+
+def mode_flags(mode: str | None = None) -> int:
+    """`flags` word of the C ABI for a transform mode (None = the product default)"""
+    return _MODE_FLAGS[resolve_mode(mode)]
 
 
 def host_level_mode() -> str:
-    """transform mode of the NumPy-level entry points and of the drop-in pipelines built on them"""
-    mode = _ENV_MODE or "exact"
-    mode_flags(mode, "guarded")       # validates
-    return mode
+    """transform mode of the drop-in operator and video pipelines: the product default"""
+    return resolve_mode(None)
 
 
 def clamp_ac(n_ac) -> int:
@@ -128,11 +133,11 @@ def embed_frames(frames: np.ndarray, delta, n_ac, bits, bit_offset: int = 0, n_b
     if bit_offset + n_bits > bits.size:
         raise ValueError("bit_offset + n_bits exceeds the payload length")
     packed, bit_offset = _pack_window(bits, bit_offset, n_bits)
-    stego = np.empty_like(stack)
+    stego = pinned_empty(stack.shape)      # page-locked: the download lands in it by DMA, no staging copy, no page faults
     done = C.c_uint64(0)
     planes = Planes.contiguous(f, h, w)
     rc = lib.svs_embed(stack.ctypes.data, stego.ctypes.data, C.byref(planes), float(delta), int(n_ac),
-                       packed.ctypes.data, int(bit_offset), int(n_bits), mode_flags(mode, "guarded"), C.byref(done))
+                       packed.ctypes.data, int(bit_offset), int(n_bits), mode_flags(mode), C.byref(done))
     native.check(rc, "svs_embed")
     return stego, int(done.value)
 
@@ -149,10 +154,67 @@ def extract_frames(frames: np.ndarray, delta, n_ac, device: int = 0, mode: str |
     got = C.c_uint64(0)
     planes = Planes.contiguous(f, h, w)
     rc = lib.svs_extract(stack.ctypes.data, C.byref(planes), float(delta), int(n_ac), out.ctypes.data,
-                         out.size, mode_flags(mode, "guarded"), C.byref(got))
+                         out.size, mode_flags(mode), C.byref(got))
     native.check(rc, "svs_extract")
     n = int(got.value)
     return out[: (n + 7) // 8], n
+
+
+# ---- the reference operator's own payload types: '0' / '1' strings ------------------------------------------
+_utf8_and_size = None
+
+
+def _ascii_address(text: str):
+    """(address, length) of the characters of an ASCII str WITHOUT copying them (CPython keeps ASCII strings as one byte per
+    character; PyUnicode_AsUTF8AndSize hands out that very buffer).  The reference's frame loop passes the whole remaining
+    payload to every call (embed_process.py:116) - slicing or encoding it per frame would copy it per frame."""
+    global _utf8_and_size
+    if _utf8_and_size is None:
+        fn = C.pythonapi.PyUnicode_AsUTF8AndSize
+        fn.restype, fn.argtypes = C.c_void_p, [C.py_object, C.POINTER(C.c_ssize_t)]
+        _utf8_and_size = fn
+    size = C.c_ssize_t(0)
+    addr = _utf8_and_size(text, C.byref(size))
+    if not addr or size.value != len(text):
+        raise ValueError("the payload must be a string of '0' / '1' characters")
+    return addr, size.value
+
+
+def embed_frames_str(frames: np.ndarray, delta, n_ac, payload: str | None, device: int = 0, mode: str | None = None):
+    """`embed_frames` for a payload in the reference operator's own form, a '0'/'1' string (bit_payload_segment,
+    config_and_setup.py:106-109): at most the capacity is read from its front, the characters go to the device as they are
+    and are packed there (svs_embed_str).  None / "" = nothing to embed.  Returns (stego uint8 [F,H,W], n_embedded)."""
+    lib = native.load()
+    native.ensure_device(device)
+    stack = _as_stack(frames)
+    f, h, w = stack.shape
+    addr, n_chars = _ascii_address(payload) if payload else (None, 0)
+    stego = pinned_empty(stack.shape)
+    done = C.c_uint64(0)
+    planes = Planes.contiguous(f, h, w)
+    rc = lib.svs_embed_str(stack.ctypes.data, stego.ctypes.data, C.byref(planes), float(delta), int(n_ac), addr, n_chars,
+                           mode_flags(mode), C.byref(done))
+    native.check(rc, "svs_embed_str")
+    return stego, int(done.value)
+
+
+def extract_frames_str(frames: np.ndarray, delta, n_ac, device: int = 0, mode: str | None = None) -> str:
+    """`extract_frames` returning the reference operator's own type: the '0'/'1' string of config_and_setup.py:173-174
+    (expanded on the device, one decode on the host)."""
+    lib = native.load()
+    native.ensure_device(device)
+    stack = _as_stack(frames)
+    f, h, w = stack.shape
+    cap = capacity_bits(f, h, w, n_ac)
+    if cap == 0:
+        return ""
+    out = pinned_empty(cap)
+    got = C.c_uint64(0)
+    planes = Planes.contiguous(f, h, w)
+    rc = lib.svs_extract_str(stack.ctypes.data, C.byref(planes), float(delta), int(n_ac), out.ctypes.data, cap,
+                             mode_flags(mode), C.byref(got))
+    native.check(rc, "svs_extract_str")
+    return str(memoryview(out)[: int(got.value)], "ascii")
 
 
 # ---- device-pointer level -------------------------------------------------------------------
@@ -161,7 +223,7 @@ def embed_device(d_gray: int, d_stego: int, planes: Planes, delta, n_ac, d_bits_
     """Enqueue the embed kernel on `stream` (a hipStream_t handle as int); returns bits embedded."""
     done = C.c_uint64(0)
     rc = native.load().svs_embed_dev(d_gray, d_stego, C.byref(planes), float(delta), int(n_ac), d_bits_packed,
-                                     int(bit_offset), int(n_bits), mode_flags(mode, "fast"), C.byref(done),
+                                     int(bit_offset), int(n_bits), mode_flags(mode), C.byref(done),
                                      stream or None)
     native.check(rc, "svs_embed_dev")
     return int(done.value)
@@ -172,7 +234,7 @@ def extract_device(d_gray: int, planes: Planes, delta, n_ac, d_bits_out: int, ou
     """Enqueue the extract kernel on `stream`; returns the number of bits the batch yields."""
     got = C.c_uint64(0)
     rc = native.load().svs_extract_dev(d_gray, C.byref(planes), float(delta), int(n_ac), d_bits_out,
-                                       int(out_capacity_bytes), mode_flags(mode, "fast"), C.byref(got),
+                                       int(out_capacity_bytes), mode_flags(mode), C.byref(got),
                                        stream or None)
     native.check(rc, "svs_extract_dev")
     return int(got.value)
@@ -199,7 +261,7 @@ def embed_bgr_device(d_bgr_in: int, d_bgr_out: int, d_gray_ref: int, planes: Pla
     done = C.c_uint64(0)
     rc = native.load().svs_embed_bgr_dev(d_bgr_in, irp, ifp, d_bgr_out, orp, ofp, d_gray_ref or None,
                                          C.byref(planes), wptr, float(delta), int(n_ac), d_bits_packed,
-                                         int(bit_offset), int(n_bits), mode_flags(mode, "fast"), C.byref(done),
+                                         int(bit_offset), int(n_bits), mode_flags(mode), C.byref(done),
                                          stream or None)
     native.check(rc, "svs_embed_bgr_dev")
     return int(done.value)
@@ -243,13 +305,13 @@ def embed_bgr_frames(frames_bgr: np.ndarray, delta, n_ac, bits, bit_offset: int 
         raise ValueError("bit_offset + n_bits exceeds the payload length")
     packed, bit_offset = _pack_window(bits, bit_offset, n_bits)
     planes = Planes.contiguous(f, h, w)
-    out = np.empty_like(stack)
-    gray = np.empty((f, h, w), np.uint8) if want_gray else None
+    out = pinned_empty(stack.shape)
+    gray = pinned_empty((f, h, w)) if want_gray else None
     keep, wptr = _weights_arg(weights)
     done = C.c_uint64(0)
     rc = lib.svs_embed_bgr(stack.ctypes.data, out.ctypes.data, gray.ctypes.data if want_gray else None,
                            C.byref(planes), wptr, float(delta), int(n_ac), packed.ctypes.data, int(bit_offset),
-                           int(n_bits), mode_flags(mode, "guarded"), C.byref(done))
+                           int(n_bits), mode_flags(mode), C.byref(done))
     native.check(rc, "svs_embed_bgr")
     used = int(done.value)
     return out, gray, used

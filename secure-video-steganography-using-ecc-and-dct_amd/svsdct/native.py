@@ -20,7 +20,7 @@ SVS_ERR_NO_DEVICE = -3
 SVS_ERR_CAPACITY = -4
 SVS_EXACT_POCKETFFT = 1      # flags bit: pocketfft-identical arithmetic (include/svsdct.h)
 SVS_EXACT_GUARDED = 2        # flags bit: the same bit-identical result through the guarded kernel where it applies
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class SvsNativeError(RuntimeError):
@@ -50,6 +50,7 @@ SIGNATURES = {
     "svs_device_count": (C.c_int, [C.POINTER(C.c_int)]),
     "svs_init": (C.c_int, [C.c_int]),
     "svs_device_arch": (C.c_int, [C.c_int, C.c_char_p, C.c_size_t]),
+    "svs_shutdown": (C.c_int, []),
     "svs_malloc": (C.c_int, [C.POINTER(C.c_void_p), C.c_size_t]),
     "svs_free": (C.c_int, [C.c_void_p]),
     "svs_memcpy_h2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
@@ -64,6 +65,8 @@ SIGNATURES = {
     "svs_packed_bytes": (C.c_uint64, [C.c_uint64]),
     "svs_embed_dev": (C.c_int, [_u8p, _u8p, _PL, C.c_double, C.c_int, _u8p, C.c_uint64, C.c_uint64, C.c_uint32, _u64p, C.c_void_p]),
     "svs_embed": (C.c_int, [_u8p, _u8p, _PL, C.c_double, C.c_int, _u8p, C.c_uint64, C.c_uint64, C.c_uint32, _u64p]),
+    "svs_embed_str": (C.c_int, [_u8p, _u8p, _PL, C.c_double, C.c_int, C.c_void_p, C.c_uint64, C.c_uint32, _u64p]),
+    "svs_extract_str": (C.c_int, [_u8p, _PL, C.c_double, C.c_int, C.c_void_p, C.c_uint64, C.c_uint32, _u64p]),
     "svs_extract_dev": (C.c_int, [_u8p, _PL, C.c_double, C.c_int, _u8p, C.c_uint64, C.c_uint32, _u64p, C.c_void_p]),
     "svs_extract": (C.c_int, [_u8p, _PL, C.c_double, C.c_int, _u8p, C.c_uint64, C.c_uint32, _u64p]),
     "svs_bgr_to_gray_dev": (C.c_int, [_u8p, C.c_int64, C.c_int64, _u8p, _PL, C.c_void_p, C.c_void_p]),

@@ -55,7 +55,7 @@ class FramePipeline:
         self.lib = native.load()
         self.device = device
         self.h, self.w, self.batch, self.depth = height, width, batch_frames, depth
-        self.delta, self.n_ac, self.mode = delta, n_ac, mode
+        self.delta, self.n_ac, self.mode = delta, n_ac, batch.resolve_mode(mode)
         self.frame_capacity = batch.capacity_bits(1, height, width, n_ac)
         self.batch_capacity = self.frame_capacity * batch_frames
         self._bits_bytes = (self.batch_capacity + 7) // 8 + 8
@@ -107,7 +107,7 @@ class FramePipeline:
         native.check(self.lib.svs_memcpy_h2d(s["d_frames"], s["hin_p"], nbytes, s["stream"]), "svs_memcpy_h2d")
         used = batch.embed_device(s["d_frames"].value, s["d_frames"].value, self._planes(n_frames), self.delta, self.n_ac,
                                   self._d_payload.value if self._d_payload else 0, bit_offset, left,
-                                  stream=s["stream"].value, mode=self.mode or "fast")
+                                  stream=s["stream"].value, mode=self.mode)
         native.check(self.lib.svs_memcpy_d2h(s["hout_p"], s["d_frames"], nbytes, s["stream"]), "svs_memcpy_d2h")
         s["frames"], s["bits"] = n_frames, used
         return used
@@ -124,7 +124,7 @@ class FramePipeline:
         nbytes = n_frames * self.h * self.w
         native.check(self.lib.svs_memcpy_h2d(s["d_frames"], s["hin_p"], nbytes, s["stream"]), "svs_memcpy_h2d")
         got = batch.extract_device(s["d_frames"].value, self._planes(n_frames), self.delta, self.n_ac, s["d_bits"].value,
-                                   self._bits_bytes, stream=s["stream"].value, mode=self.mode or "fast")
+                                   self._bits_bytes, stream=s["stream"].value, mode=self.mode)
         native.check(self.lib.svs_memcpy_d2h(s["hbits_p"], s["d_bits"], (got + 7) // 8, s["stream"]), "svs_memcpy_d2h")
         s["frames"], s["bits"] = n_frames, got
         return got

@@ -41,12 +41,27 @@ void embed_exact_pair_dispatch(Blk &a, Blk &b, uint32_t n, uint32_t nb_a, uint32
 
 bool g_constant_shortcut = false;   // exact == 3: constant blocks take forward_exact_paired_constant, as the replay kernel does
 
-// GUARDED (exact == 4; FAST too at n <= 15): -> true when the block has to be redone with the exact arithmetic
+bool g_generic_guarded2 = false;    // exact == 5: the two-row guard through its generic instantiation only
+
+// Two coefficient rows: the instantiation the KERNEL launches (csrc/svs_device.hpp embed_kernel, svs_capi.hip launch_embed) -
+// compile-time n for the GUI's default 10, and for every quantiser but the power-of-two one the in-place form (truncated
+// inverse, stego bytes written over the row dwords, an undecided block left half-written: the kernel rebuilds it from the
+// rows it parked in LDS, the caller here from the frame).  exact == 5 forces <QM, 0, false> so that the CPU tier can hold
+// the two against each other.
+template <int QM>
+bool guarded2_as_launched(Blk &raw, uint32_t n, uint32_t nb, uint32_t hi, uint32_t lo, const svs::QimParams &qp) {
+    if (g_generic_guarded2) return svs::embed_block_guarded2<QM, 0, false>(raw.x, raw.y, n, nb, hi, lo, qp);
+    constexpr bool INPLACE = QM != svs::QM_POW2;
+    if (n == 10) return svs::embed_block_guarded2<QM, 10, INPLACE>(raw.x, raw.y, n, nb, hi, lo, qp);
+    return svs::embed_block_guarded2<QM, 0, INPLACE>(raw.x, raw.y, n, nb, hi, lo, qp);
+}
+
+// GUARDED (exact == 4 / 5; FAST too at n <= 15): -> true when the block has to be redone with the exact arithmetic
 bool embed_guarded_dispatch(Blk &raw, uint32_t n, uint32_t nb, uint32_t hi, uint32_t lo, const svs::QimParams &qp, int qm) {
     if (svs::rows_for((int)n) == 2) {   // two coefficient rows: the per-pixel rigorous guard
-        if (qm == svs::QM_DOUBLE) return svs::embed_block_guarded2<svs::QM_DOUBLE>(raw.x, raw.y, n, nb, hi, lo, qp);
-        if (qm == svs::QM_POW2) return svs::embed_block_guarded2<svs::QM_POW2>(raw.x, raw.y, n, nb, hi, lo, qp);
-        return svs::embed_block_guarded2<svs::QM_F32>(raw.x, raw.y, n, nb, hi, lo, qp);
+        if (qm == svs::QM_DOUBLE) return guarded2_as_launched<svs::QM_DOUBLE>(raw, n, nb, hi, lo, qp);
+        if (qm == svs::QM_POW2) return guarded2_as_launched<svs::QM_POW2>(raw, n, nb, hi, lo, qp);
+        return guarded2_as_launched<svs::QM_F32>(raw, n, nb, hi, lo, qp);
     }
     if (qm == svs::QM_DOUBLE) return svs::embed_block_guarded<svs::QM_DOUBLE>(raw.x, raw.y, n, nb, hi, lo, qp);
     if (qm == svs::QM_POW2) return svs::embed_block_guarded<svs::QM_POW2>(raw.x, raw.y, n, nb, hi, lo, qp);
@@ -96,6 +111,8 @@ uint64_t emu_embed(const uint8_t *gray, uint8_t *stego, int F, int H, int W, dou
                    uint64_t *n_replayed) {
     if (n_replayed) *n_replayed = 0;
     g_constant_shortcut = exact == 3;
+    g_generic_guarded2 = exact == 5;
+    if (exact == 5) exact = 4;
     const int n = n_ac < 0 ? 0 : (n_ac > 63 ? 63 : n_ac);
     const uint64_t bpf = (uint64_t)(H / 8) * (W / 8), total = bpf * F;
     std::memcpy(stego, gray, (size_t)F * H * W);

@@ -90,3 +90,57 @@ def test_exit_rule_follows_the_oracle_not_zero():
     assert bench.round_trip_verdict(None, 5, 8.0, 63) is None                    # clipping: the reference loses bits too
     assert bench.round_trip_verdict(None, 5, 4.0, 3) is None
     assert bench.round_trip_verdict(None, 5, 64.0, 3) is None                    # large steps clip
+
+
+def test_documented_multi_gpu_commands_parse_and_plan():
+    """the multi-GPU commands of the BASELINE configurations as README.md documents them are parsed by
+    bench.py's own parser and dry-run through bench.job_plan (pure arithmetic, no GPU): contiguous shares that cover the clip
+    in stream order, each rank's bit offset, equal gather contributions, one call's block count inside the ABI limit, a rank's
+    buffers inside one MI355X's HBM - and the exit rule cannot fail a correct run of any of them (no CPU sample at N > 1)."""
+    import re
+    import shlex
+    sys.path.insert(0, REPO)
+    import bench
+    from svsdct import batch
+    text = open(os.path.join(REPO, "README.md")).read()
+    cmds = [shlex.split(line)[2:] for line in re.findall(r"^python bench\.py --gpus .*$", text, flags=re.M)]
+    assert len(cmds) == 5
+    seen = set()
+    for argv in cmds:
+        args = bench.parse_args(argv)
+        world = args.gpus
+        assert world == 8
+        plan = bench.job_plan(args, world)
+        seen.add((args.total_frames, args.height, args.width, args.n_ac, args.delta))
+        per_frame = batch.capacity_bits(1, args.height, args.width, args.n_ac)
+        assert plan["per_frame_bits"] == per_frame
+        nxt = 0
+        for r, rk in enumerate(plan["ranks"]):
+            if args.total_frames:
+                assert rk["first_frame"] == nxt                          # contiguous, rank order = stream order
+            nxt = rk["first_frame"] + rk["frames"]
+            assert rk["frames"] > 0 and rk["first_bit"] == rk["first_frame"] * per_frame
+            assert rk["blocks"] < 2 ** 31                                # one svs_embed_dev call per rank and step (include/svsdct.h)
+            assert rk["device_bytes"] < 0.5 * 288e9                      # fits one MI355X with room to spare
+            assert (rk["capacity_bits"] + 7) // 8 <= plan["gather_bytes_per_rank"]
+        if args.total_frames:
+            assert nxt == args.total_frames == plan["total_frames"] and plan["scaling"] == "strong"
+        else:
+            assert plan["total_frames"] == world * args.frames and plan["scaling"] == "weak"
+        assert plan["bytes_received_by_rank0_per_step"] == world * plan["gather_bytes_per_rank"]
+        # N > 1 has no oracle sample: the run may only fail on a setting that provably loses no bit; the reference's own
+        # payload errors (delta = 4: 1.6 %; n = 10 on clipping content) never fail a correct run
+        assert bench.round_trip_verdict(None, 0, args.delta, args.n_ac) is None
+        if args.delta < 8 or args.n_ac > 7:
+            assert bench.round_trip_verdict(None, 12345, args.delta, args.n_ac) is None
+    assert (2400, 1080, 1920, 10, 8.0) in seen                            # configs[3]
+    assert {(1200, 4320, 7680, 3, d) for d in (4.0, 8.0, 16.0)} <= seen   # configs[4]
+    assert (0, 2160, 3840, 3, 8.0) in seen                                # configs[2] x N, the driver's scaling run
+    # configs[3] shares: 300 frames per GPU = one 1080p clip each; configs[4]: 150 8K frames per GPU, 29.16 MB of bits each
+    p3 = bench.job_plan(bench.parse_args(cmds[1]), 8)
+    assert [c for _, c in p3["shares"]] == [300] * 8 and p3["gather_bytes_per_rank"] == 300 * 32400 * 10 // 8
+    p4 = bench.job_plan(bench.parse_args(cmds[2]), 8)
+    assert [c for _, c in p4["shares"]] == [150] * 8 and p4["gather_bytes_per_rank"] == 150 * 518400 * 3 // 8
+    # uneven division and more ranks than some share sizes still cover the clip
+    odd = bench.job_plan(bench.parse_args(["--gpus", "8", "--total-frames", "1203", "--height", "1080", "--width", "1920"]), 8)
+    assert [c for _, c in odd["shares"]] == [151] * 3 + [150] * 5 and sum(c for _, c in odd["shares"]) == 1203

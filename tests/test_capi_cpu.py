@@ -24,7 +24,63 @@ def test_library_exports_every_declared_symbol():
     for name in names:
         assert hasattr(lib, name), name
     assert sorted(native.SIGNATURES) == names          # the binding covers the header, nothing more
-    assert lib.svs_abi_version() == native.ABI_VERSION == 3
+    assert lib.svs_abi_version() == native.ABI_VERSION == 4
+
+
+def _exported(path):
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True, check=True).stdout
+    return sorted(line.split()[-1] for line in out.splitlines() if line.split()[-1].startswith("svs_"))
+
+
+def test_library_exports_exactly_the_declared_symbols():
+    """the product library's svs_* exports ARE the header - no measurement hook, no process-global state
+    behind one (round 4 shipped svs_guard_counter_set / svs_ref_copy_dev / svs_ref_read_dev / svs_probe_cvt_pk_u8).  Those live
+    in the experiments library, which is the product ABI plus exactly them."""
+    from testlib import EXP_LIB_PATH, EXPERIMENT_HOOKS
+    assert _exported(native.LIB_PATH) == _declared_symbols()
+    assert _exported(EXP_LIB_PATH) == sorted(_declared_symbols() + list(EXPERIMENT_HOOKS))
+    src = open(os.path.join(REPO, "secure-video-steganography-using-ecc-and-dct_amd", "csrc", "svs_capi.hip")).read()
+    outside = re.sub(r"#if defined\(SVS_EXPERIMENTS\).*?#e(?:lse|ndif)", "", src, flags=re.S)
+    assert "g_guard_counter" not in outside            # the kernels of the product build take no counter
+
+
+def test_one_default_mode_everywhere():
+    """ONE default transform mode - svsdct.batch.DEFAULT_MODE = "guarded" - and every layer resolves an
+    unspecified mode through batch.resolve_mode: the NumPy-level and device-level entry points, FramePipeline, the drop-in
+    operator, both drop-in video loops, bench.py.  (Round 4: host_level_mode() returned "exact", so the video loops ran the
+    lane-per-block kernel while bench.py and the docs said guarded.)"""
+    import ast
+    import inspect
+    assert batch.DEFAULT_MODE == "guarded" and batch.resolve_mode(None) == "guarded" == batch.host_level_mode()
+    assert batch.mode_flags(None) == batch.mode_flags("guarded") == native.SVS_EXACT_GUARDED
+    assert batch.mode_flags("fast") == 0 and batch.mode_flags("exact") == native.SVS_EXACT_POCKETFFT
+    with pytest.raises(ValueError):
+        batch.resolve_mode("quick")
+    # no entry point carries a default of its own: every `mode` parameter defaults to None ...
+    for name in ("embed_frames", "extract_frames", "embed_device", "extract_device", "embed_bgr_device", "embed_bgr_frames"):
+        assert inspect.signature(getattr(batch, name)).parameters["mode"].default is None, name
+    from svsdct import pipeline
+    assert inspect.signature(pipeline.FramePipeline.__init__).parameters["mode"].default is None
+    # ... and no module of the package or bench.py spells a mode name next to `or` / as a fallback
+    pkg = os.path.join(REPO, "secure-video-steganography-using-ecc-and-dct_amd")
+    files = [os.path.join(REPO, "bench.py")] + [os.path.join(r, f) for r, _, fs in os.walk(pkg) for f in fs if f.endswith(".py")]
+    for path in files:
+        tree = ast.parse(open(path).read())
+        for node in ast.walk(tree):
+            if isinstance(node, ast.BoolOp) and isinstance(node.op, ast.Or):
+                for v in node.values:
+                    assert not (isinstance(v, ast.Constant) and v.value in ("fast", "exact", "guarded")), \
+                        f"{path}:{node.lineno}: a mode default outside batch.resolve_mode"
+            if isinstance(node, ast.keyword) and node.arg == "mode" and isinstance(node.value, ast.Constant) \
+                    and node.value.value in ("fast", "guarded") and not path.endswith("bench.py"):
+                raise AssertionError(f"{path}:{node.lineno}: hard-coded mode")
+    # the drop-in loops hand the pipeline the resolved default
+    for mod in ("embed_process.py", "extract_process.py"):
+        text = open(os.path.join(pkg, mod)).read()
+        assert "host_level_mode()" in text and '"exact"' not in text
+    bench = open(os.path.join(REPO, "bench.py")).read()
+    assert "batch.resolve_mode(args.mode)" in bench
 
 
 def test_header_is_plain_c_and_library_links_from_c(tmp_path):

@@ -1,10 +1,11 @@
 """GPU tier (-m gpu): the HIP kernels, called through the C ABI (libsvsdct.so), against the
 pinned oracle, the reference's golden vectors and size-independent properties at BASELINE sizes.
 
-Parity bar (BASELINE.json north_star): extracted payload bits bit-exact; stego-frame PSNR within
-+-0.01 dB of the reference's.  Stego PIXELS are not required to be identical (exact
-rounding ties resolve by pocketfft's float32 noise) - the number that differ is written to
-gpurun_out/parity_report.json for the record.
+Parity bar: IDENTITY.  BASELINE.json's north_star asks for bit-exact extracted bits and a stego PSNR within +-0.01 dB of
+the reference's; since round 4 every embed mode reproduces the reference's stego PIXELS (pocketfft's float32 noise, exact
+rounding ties and truncation artefacts included - SURVEY N4, N6), so the tests assert equality of arrays / zero squared
+difference wherever both sides can be computed, never a PSNR tolerance between two of this build's modes.  PSNR appears only
+as the size-independent band check of the full-batch test and in the report written to gpurun_out/parity_report.json.
 """
 import ctypes as C
 import json
@@ -14,14 +15,13 @@ import numpy as np
 import pytest
 
 from testlib import (CONTRACT_POINTS, GUARDED_POINTS, guarded_soak_cases, ORIGINAL_COVERS, REPO, case_inputs, contract_payloads,
-                     emu_embed, emu_extract, exact_tie_mask, golden_bits, natural_like, psnr_gap, sha, single_frame_cases,
-                     structured_covers)
+                     emu_embed, emu_extract, exact_tie_mask, experiments_library, golden_bits, natural_like, sha,
+                     single_frame_cases, structured_covers, using_library)
 from oracle import qim_dct_oracle as orc
 from svsdct import batch, native, synth
 from svsdct.native import Planes
 
 pytestmark = pytest.mark.gpu
-PSNR_TOL_DB = 0.01
 _REPORT = {}
 
 
@@ -102,20 +102,17 @@ def test_exact_mode_on_natural_like_content(n_ac, delta, mode):
     assert (want[0, 1080 // 2: 1080 // 2 + 64, : 1920 // 3 - 8] != flat).any() or delta == 4
     packed, n_bits = batch.extract_frames(stego, delta, n_ac, mode="exact")
     assert np.array_equal(np.unpackbits(packed, count=n_bits), orc.batch_extract_bits(want, delta, n_ac))
-    # fast mode on the same content: identical extracted bits from the reference's frames and from the never-embedded
-    # cover (no masks: quantiser inputs near a tie take the exact path), stego PSNR within tolerance (blocks with a
-    # structurally zero change are replayed with the exact arithmetic)
+    # flags = 0 on the same content: identical extracted bits from the reference's frames and from the never-embedded
+    # cover (no masks: quantiser inputs near a tie take the exact path), and the reference's stego pixels
     for src in (want, cover):
         packed, n_bits = batch.extract_frames(src, delta, n_ac, mode="fast")
         assert np.array_equal(np.unpackbits(packed, count=n_bits), orc.batch_extract_bits(src, delta, n_ac))
     fast, used_f = batch.embed_frames(cover, delta, n_ac, payload, mode="fast")
-    assert used_f == want_used
+    assert used_f == want_used and np.array_equal(fast, want)
     for k in range(2):
-        a, b = orc.psnr_u8(cover[k], fast[k]), orc.psnr_u8(cover[k], want[k])
-        assert abs(a - b) <= PSNR_TOL_DB, (k, a, b)
         _REPORT[f"natural_like_n{n_ac}_d{delta}_frame{k}_{mode}"] = {
-            "pixels": h * w, "pixels_differing_from_reference": int((fast[k] != want[k]).sum()), "psnr": a,
-            "psnr_reference": b}
+            "pixels": h * w, "pixels_differing_from_reference": 0, "psnr": orc.psnr_u8(cover[k], fast[k]),
+            "psnr_reference": orc.psnr_u8(cover[k], want[k])}
 
 
 @pytest.mark.parametrize("n_ac,delta", CONTRACT_POINTS)
@@ -138,7 +135,6 @@ def test_fast_mode_contract_on_structured_content(n_ac, delta):
             _, ref, ref_used = orc.frame_embed(cover, delta, payload, n_ac)
             assert used == ref_used == cap
             a, b = orc.psnr_u8(cover, stego[0]), orc.psnr_u8(cover, ref)
-            assert psnr_gap(a, b) <= PSNR_TOL_DB, (name, pname, a, b)
             assert np.array_equal(stego[0], ref), (name, pname)           # every embed mode gives the reference's pixels (round 4)
             replayed = []
             emu, _ = emu_embed(cover, delta, n_ac, payload, replayed=replayed)
@@ -172,23 +168,24 @@ def test_guarded_mode_equals_reference_on_structured_content(n_ac, delta):
     reference, pixel for pixel, on 14 content
     classes (flat, letterboxed, one-dimensional, posterised, text-like, dark / bright noise, exact cancellations ...) at
     every setting incl. the ends of its delta range; the share of blocks it redid exactly is recorded per class."""
-    lib = native.load()
-    lib.svs_guard_counter_set.restype = C.c_int
-    lib.svs_guard_counter_set.argtypes = [C.c_void_p]
+    exp = experiments_library()           # the replay counter is a hook of the experiments library (same kernel sources)
     h, w = 544, 960
     d_cnt = _Dev(8)
     for name, cover in structured_covers(h, w).items():
         cap = batch.capacity_bits(1, h, w, n_ac)
         payload = synth.synthetic_bits(cap, seed=n_ac * 100 + int(delta))
-        native.check(lib.svs_memset(d_cnt.ptr, 0, 8, None), "memset")
-        native.check(lib.svs_stream_synchronize(None), "sync")
-        lib.svs_guard_counter_set(d_cnt.ptr)
-        try:
-            stego, used = batch.embed_frames(cover, delta, n_ac, payload, mode="guarded")
-        finally:
-            lib.svs_guard_counter_set(None)
+        stego, used = batch.embed_frames(cover, delta, n_ac, payload, mode="guarded")          # the product library
         _, ref, ref_used = orc.frame_embed(cover, delta, payload, n_ac)
         assert used == ref_used and np.array_equal(stego[0], ref), name
+        native.check(exp.svs_memset(d_cnt.ptr, 0, 8, None), "memset")
+        native.check(exp.svs_stream_synchronize(None), "sync")
+        exp.svs_guard_counter_set(d_cnt.ptr)
+        try:
+            with using_library(exp):
+                counted, used_c = batch.embed_frames(cover, delta, n_ac, payload, mode="guarded")
+        finally:
+            exp.svs_guard_counter_set(None)
+        assert used_c == ref_used and np.array_equal(counted[0], ref), name
         if n_ac <= 7:
             fast, used_f = batch.embed_frames(cover, delta, n_ac, payload, mode="fast")  # n <= 7: the same launch
             assert used_f == ref_used and np.array_equal(fast[0], ref), name
@@ -249,9 +246,9 @@ def test_golden_vectors(golden):
         # (c) a receiver running the reference reads the same bits from our frame as from the reference's
         assert np.array_equal(orc.frame_extract_bits(stego, delta, n_ac)[:used],
                               orc.frame_extract_bits(ref_stego, delta, n_ac)[:used]), name
-        # (d) PSNR
+        # (d) the PSNR the reference recorded for this case (identity implies it; the golden JSON's number is the reference's own)
         if np.isfinite(info["psnr"]):
-            assert abs(orc.psnr_u8(gray, stego) - info["psnr"]) <= PSNR_TOL_DB, name
+            assert orc.psnr_u8(gray, stego) == pytest.approx(info["psnr"], abs=1e-9), name
         else:
             assert np.array_equal(stego, gray), name
         # (e) extraction from the never-embedded cover: identical as well, rounding ties of c/delta included
@@ -322,7 +319,6 @@ def test_full_size_round_trip_and_oracle_agreement(shape, n_ac, delta, frames):
         assert np.array_equal(got[k * per:(k + 1) * per], orc.frame_extract_bits(stego[k], delta, n_ac))
         _, ref_stego, _ = orc.frame_embed(cover[k], delta, payload[k * per:(k + 1) * per], n_ac)
         a, b = orc.psnr_u8(cover[k], stego[k]), orc.psnr_u8(cover[k], ref_stego)
-        assert abs(a - b) <= PSNR_TOL_DB, (a, b)
         assert np.array_equal(stego[k], ref_stego), (k, "flags = 0 must give the reference's pixels")
         _REPORT[f"full_{h}x{w}_n{n_ac}_d{delta}_frame{k}"] = {
             "pixels": h * w, "pixels_differing_from_reference": int((stego[k] != ref_stego).sum()),
@@ -344,23 +340,18 @@ def test_baseline_config5_shape_8k_delta_sweep(delta):
     ref_bits = orc.frame_extract_bits(ref_stego, delta, n_ac)
     ref_ber = int((ref_bits != payload).sum())
     assert (ref_ber == 0) == (delta >= 8)                     # only delta = 4 loses bits
-    # exact mode: everything identical
-    stego_x, used = batch.embed_frames(cover, delta, n_ac, payload, mode="exact")
-    assert used == cap and np.array_equal(stego_x[0], ref_stego)
-    # fast mode: same bits as the oracle on its own frames, same payload errors as the reference, same PSNR
-    stego, used = batch.embed_frames(cover, delta, n_ac, payload, mode="fast")
-    packed, n_bits = batch.extract_frames(stego, delta, n_ac, mode="fast")
-    got = np.unpackbits(packed, count=n_bits)
-    assert np.array_equal(got, orc.frame_extract_bits(stego[0], delta, n_ac))
-    assert abs(orc.psnr_u8(cover[0], stego[0]) - orc.psnr_u8(cover[0], ref_stego)) <= PSNR_TOL_DB
-    ber = int((got != payload).sum())
-    # the payload errors of OUR stego frame are exactly those the reference's receiver makes on it (asserted bit for bit
-    # above); against the reference's own stego frame the count can differ by the handful of pixels float32 noise decides
-    assert ber == int((orc.frame_extract_bits(stego[0], delta, n_ac) != payload).sum())
-    assert ber == 0 if delta >= 8 else abs(ber - ref_ber) <= 0.002 * ref_ber
-    _REPORT[f"8k_n3_d{delta}"] = {"pixels": h * w, "pixels_differing_from_reference": int((stego[0] != ref_stego).sum()),
+    # every mode: the reference's frame, pixel for pixel - hence its PSNR, its extracted bits and its payload errors (delta = 4:
+    # the reference's own 1.6 %, at the reference's positions)
+    for mode in ("exact", "guarded", "fast"):
+        stego, used = batch.embed_frames(cover, delta, n_ac, payload, mode=mode)
+        assert used == cap and np.array_equal(stego[0], ref_stego), mode
+        packed, n_bits = batch.extract_frames(stego, delta, n_ac, mode=mode)
+        got = np.unpackbits(packed, count=n_bits)
+        assert np.array_equal(got, ref_bits), mode
+        assert int((got != payload).sum()) == ref_ber, mode
+    _REPORT[f"8k_n3_d{delta}"] = {"pixels": h * w, "pixels_differing_from_reference": 0,
                                   "psnr": orc.psnr_u8(cover[0], stego[0]), "psnr_reference": orc.psnr_u8(cover[0], ref_stego),
-                                  "payload_bit_errors": ber, "payload_bit_errors_reference": ref_ber}
+                                  "payload_bit_errors": ref_ber, "payload_bit_errors_reference": ref_ber}
 
 
 @pytest.mark.parametrize("f,h,w,n_ac,delta,band", [
@@ -405,16 +396,11 @@ def test_full_baseline_batch_on_device_properties(f, h, w, n_ac, delta, band):
     assert errors(d_x2) == 0
     assert batch.extract_device(d_b.ptr.value, planes, delta, n_ac, d_x2.ptr.value, nbytes, mode="fast") == cap
     assert errors(d_x2) == 0                                                  # fast extract of exact stego
-    exact_vs_fast = sse(d_a, d_b).copy()
-    # the contract between the modes: every frame's PSNR within 0.01 dB (the stego planes differ where float32 noise
-    # decides a floor or a quantiser near-tie - about 1e-5 of the pixels at n = 3, 1e-3 at n = 10)
-    psnr_exact = 10 * np.log10(255.0 ** 2 * h * w / sse(d_gray, d_b).astype(np.float64))
-    assert np.abs(psnr_exact - psnr).max() <= PSNR_TOL_DB, float(np.abs(psnr_exact - psnr).max())
+    # between the modes: identity - zero squared difference on every frame of the batch (5 Gpixel)
+    assert int(sse(d_a, d_b).sum()) == 0
     _REPORT[f"full_baseline_batch/{w}x{h}x{f}_n{n_ac}_d{delta:g}"] = {"frames": f, "bits": int(cap), "payload_bit_errors": 0,
                                       "psnr_db_min_max": [float(psnr.min()), float(psnr.max())],
-                                      "fast_vs_exact_psnr_delta_db_max": float(np.abs(psnr_exact - psnr).max()),
-                                      "fast_vs_exact_stego_squared_difference_per_frame_mean_max":
-                                          [float(exact_vs_fast.mean()), int(exact_vs_fast.max())]}
+                                      "default_vs_exact_stego_squared_difference": 0}
 
 
 def test_extreme_quantiser_steps():
@@ -446,8 +432,6 @@ def test_extreme_quantiser_steps():
             bits = synth.synthetic_bits(batch.capacity_bits(1, 544, 960, n_ac), seed=3)
             ref, _ = orc.batch_embed(big, delta, bits, n_ac)
             fast, _ = batch.embed_frames(big, delta, n_ac, bits, mode="fast")
-            a, b = orc.psnr_u8(big[0], fast[0]), orc.psnr_u8(big[0], ref[0])
-            assert abs(a - b) <= PSNR_TOL_DB, (delta, n_ac, a, b)
             assert np.array_equal(fast, ref), (delta, n_ac)     # n <= 15: FAST is the rigorous arithmetic (exact kernels below 0.25)
 
 
@@ -887,7 +871,7 @@ def test_drop_in_operator_matches_reference_contract(golden):
     g, stego, used = cs.proses_frame_qim_dct(gray, "embed", 20, pstr + "0101", num_ac_coeffs_to_use=10)
     assert used == info["used"] and g is not gray and np.array_equal(g, gray)
     assert stego.dtype == np.uint8 and stego.shape == gray.shape
-    assert np.array_equal(stego, arrays["G1_n10_d20/stego"])           # the operator defaults to EXACT mode
+    assert np.array_equal(stego, arrays["G1_n10_d20/stego"])           # the operator runs the product default (guarded): the reference's pixels
     text = cs.proses_frame_qim_dct(stego, "extract", 20, enable_debug_prints_extract=False, num_ac_coeffs_to_use=10)
     assert isinstance(text, str) and text == pstr
     assert cs.proses_frame_qim_dct(arrays["G1_n10_d20/stego"], "extract", 20, num_ac_coeffs_to_use=10) == \
@@ -897,6 +881,15 @@ def test_drop_in_operator_matches_reference_contract(golden):
         cs.proses_frame_qim_dct(np.zeros((8, 8, 4), np.uint8), "extract", 8)
     g, s, used = cs.proses_frame_qim_dct(gray, "embed", 20, None, num_ac_coeffs_to_use=10)
     assert used == 0 and np.array_equal(s, gray)
+    # every single-frame golden through the operator as the reference's callers use it ('0'/'1' strings; degenerate cases too:
+    # delta <= 0 and n = 0 with a non-empty payload round-trip every block, an empty or None payload copies the frame)
+    for name in single_frame_cases(meta):
+        info_k, gray_k, payload_k = case_inputs(arrays, meta, name)
+        seg = (orc.bits_to_str(payload_k) if payload_k.size else "") if info_k["payload_len"] is not None else None
+        g, s, used = cs.proses_frame_qim_dct(gray_k, "embed", info_k["delta"], seg, num_ac_coeffs_to_use=info_k["n_ac"])
+        assert used == info_k["used"] and sha(s) == info_k["stego_sha256"] and np.array_equal(g, gray_k), name
+        out = cs.proses_frame_qim_dct(s, "extract", info_k["delta"], num_ac_coeffs_to_use=info_k["n_ac"])
+        assert out == orc.bits_to_str(golden_bits(arrays, name, "ext_stego", info_k["ext_stego_len"])), name
     # default n = 63, delta as float
     g, s, used = cs.proses_frame_qim_dct(gray, "embed", 7.5, pstr)
     assert used == len(pstr)
@@ -975,3 +968,220 @@ def test_embed_calls_are_stateless_across_sizes_streams_and_host_threads():
     for t in threads:
         t.join()
     assert not failures, failures
+
+
+# ---- the host-pointer boundary: per-thread staging context, chunked full-duplex transfers -------------------
+def _pinned(shape):
+    from svsdct.hostmem import pinned_empty
+    return pinned_empty(shape)
+
+
+@pytest.mark.parametrize("chunk_kb", [8, 32, 4096])
+def test_host_pointer_calls_chunked_staging_pitched_pinned_and_pageable(chunk_kb, monkeypatch):
+    """svs_embed / svs_extract move the batch in chunks over three streams of a per-thread context (csrc/svs_capi.hip).  With
+    the experiments library's SVS_STAGE_CHUNK_KB the chunks become bands of 32 rows (8 KB), groups of three frames (32 KB) or
+    the whole batch (4 MB) of a pitched five-frame clip with an odd block count per row; budgets that end in the first chunk,
+    inside a later one, exactly on a chunk boundary and beyond the capacity; pageable and page-locked buffers on either side.
+    Every result equals the oracle's, padding bytes of the caller's stego buffer stay untouched, n_embedded adds up."""
+    exp = experiments_library()
+    monkeypatch.setenv("SVS_STAGE_CHUNK_KB", str(chunk_kb))
+    f, h, w, n_ac, delta = 5, 64, 136, 10, 8
+    rp, fp = 144, 64 * 144 + 64
+    planes = Planes(f, h, w, 0, rp, fp)
+    span = (f - 1) * fp + (h - 1) * rp + w
+    cover = synth.synthetic_frames(f, h, w, seed=5, lo=0, span=256)
+    cover[1, :16] = 200                                                   # flat blocks: replayed exactly inside the launch
+    cap = batch.capacity_bits(f, h, w, n_ac)
+    per_frame = cap // f
+    budgets = [0, 7, per_frame // 2 - 3, per_frame, 2 * per_frame + 170 * n_ac // 2, cap - 1, cap + 9]
+    rng = np.random.default_rng(chunk_kb)
+    for budget in budgets:
+        for in_pinned, out_pinned in ((False, False), (True, True), (False, True), (True, False)):
+            off = int(rng.integers(0, 70))
+            bits = rng.integers(0, 2, off + budget).astype(np.uint8)
+            want, want_used = orc.batch_embed(cover, delta, bits[off:], n_ac)
+            src = _pinned(f * fp) if in_pinned else np.empty(f * fp, np.uint8)
+            dst = _pinned(f * fp) if out_pinned else np.empty(f * fp, np.uint8)
+            src[:] = 0x11
+            dst[:] = 0xA5
+            for k in range(f):
+                src[k * fp:k * fp + h * rp].reshape(h, rp)[:, :w] = cover[k]
+            packed = batch.pack_bits(bits)
+            used = C.c_uint64(0)
+            for flags in (native.SVS_EXACT_GUARDED, native.SVS_EXACT_POCKETFFT):
+                dst[:] = 0xA5
+                rc = exp.svs_embed(src.ctypes.data, dst.ctypes.data, C.byref(planes), float(delta), n_ac, packed.ctypes.data, off,
+                                   budget, flags, C.byref(used))
+                assert rc == 0, exp.svs_last_error()
+                assert used.value == want_used == min(budget, cap)
+                got = np.stack([dst[k * fp:k * fp + h * rp].reshape(h, rp)[:, :w] for k in range(f)])
+                assert np.array_equal(got, want), (budget, in_pinned, out_pinned, flags)
+                mask = np.ones(f * fp, bool)
+                for k in range(f):
+                    for y in range(h):
+                        mask[k * fp + y * rp:k * fp + y * rp + w] = False
+                assert (dst[mask] == 0xA5).all()                          # padding of the caller's buffer left alone
+            # and back: extraction of the pitched stego frames through the host pointers
+            out = _pinned((cap + 7) // 8 + 8) if out_pinned else np.zeros((cap + 7) // 8 + 8, np.uint8)
+            got_bits = C.c_uint64(0)
+            rc = exp.svs_extract(dst.ctypes.data, C.byref(planes), float(delta), n_ac, out.ctypes.data, out.size,
+                                 native.SVS_EXACT_GUARDED, C.byref(got_bits))
+            assert rc == 0 and got_bits.value == cap
+            assert np.array_equal(np.unpackbits(out, count=cap), orc.batch_extract_bits(want, delta, n_ac))
+    assert span <= f * fp
+    assert exp.svs_shutdown() == 0                                        # the thread's context goes; the next call rebuilds it
+    stego, used = batch.embed_frames(cover, delta, n_ac, synth.synthetic_bits(cap, seed=1))
+    assert used == cap
+
+
+def test_host_pointer_calls_product_library_large_batches_and_shutdown():
+    """The product library's own chunking (4 MB): 4K frames go in two bands each, 1080p frames in pairs, 8K in eight bands;
+    pageable NumPy input, page-locked output from the package's pool; delta <= 0 with a non-empty payload (every chunk is
+    round-tripped by the exact kernel) and an empty payload (pure copy); buffers grow and shrink between calls; svs_shutdown
+    in between."""
+    from svsdct import hostmem
+    lib = native.load()
+    for (f, h, w, n_ac, delta) in ((3, 2160, 3840, 3, 8), (5, 1080, 1920, 10, 20), (1, 4320, 7680, 3, 16), (2, 64, 96, 63, 4)):
+        cover = synth.synthetic_frames(f, h, w, seed=f + n_ac)
+        cap = batch.capacity_bits(f, h, w, n_ac)
+        budget = cap - cap // (2 * f) - 5                                # ends inside the last frame, in its first half
+        bits = synth.synthetic_bits(budget, seed=h)
+        want, want_used = orc.batch_embed(cover[:1], delta, bits[:cap // f], n_ac)     # oracle on frame 0 (seconds at 8K)
+        stego, used = batch.embed_frames(cover, delta, n_ac, bits)
+        assert used == budget and np.array_equal(stego[0], want[0])
+        # the device-pointer call over the whole batch is the yardstick for the rest
+        d_in, d_bits = _Dev(cover.nbytes), _Dev(batch.pack_bits(bits).nbytes)
+        d_in.put(cover)
+        d_bits.put(batch.pack_bits(bits))
+        assert batch.embed_device(d_in.ptr.value, d_in.ptr.value, Planes.contiguous(f, h, w), delta, n_ac, d_bits.ptr.value, 0, budget) == budget
+        assert np.array_equal(d_in.get().reshape(cover.shape), stego)
+        packed, n_bits = batch.extract_frames(stego, delta, n_ac)
+        assert n_bits == cap and np.array_equal(np.unpackbits(packed, count=budget), bits)
+        if h == 1080:
+            assert lib.svs_shutdown() == 0
+            same, _ = batch.embed_frames(cover, delta, n_ac, bits)
+            assert np.array_equal(same, stego)
+            zero, used0 = batch.embed_frames(cover, 0, n_ac, bits)        # delta <= 0: nothing embedded, every block round-tripped
+            assert used0 == 0 and np.array_equal(zero[:1], orc.batch_embed(cover[:1], 0, bits, n_ac)[0])
+            assert not np.array_equal(zero, cover)
+            none, used0 = batch.embed_frames(cover, delta, n_ac, np.zeros(0, np.uint8))
+            assert used0 == 0 and np.array_equal(none, cover)
+    assert hostmem.stats["reused"] > 0                                    # result arrays cycle through the pinned pool
+    hostmem.trim()
+
+
+def test_integration_md_section_b_stub_runs_as_written(golden):
+    """INTEGRATION.md section B is the reference-side binding a maintainer would paste into the reference's
+    config_and_setup.py.  The fenced block is extracted from the document, pointed at lib/libsvsdct.so and executed as
+    written in a namespace that has what the reference's module has at that point (`np`; no cv2 - it is absent here, and the
+    2-D branch does not need it); the resulting proses_frame_qim_dct is run over goldens G1, G2, G5: stego sha256, bit counts
+    and extracted strings are the reference's (config_and_setup.py:106-109,172,174)."""
+    import re
+    text = open(os.path.join(REPO, "INTEGRATION.md")).read()
+    section = text[text.index("## B."):]
+    block = re.search(r"```python\n(.*?)```", section, flags=re.S).group(1)
+    assert '"/path/to/libsvsdct.so"' in block and "def proses_frame_qim_dct(" in block and "svs_embed_str" in block
+    block = block.replace("/path/to/libsvsdct.so", native.LIB_PATH)
+    ns = {"np": np, "__name__": "reference_config_and_setup"}
+    exec(compile(block, "INTEGRATION.md#B", "exec"), ns)     # noqa: S102 - our own document
+    op = ns["proses_frame_qim_dct"]
+    assert "cv2" not in ns
+    arrays, meta = golden
+    ran = 0
+    for name in single_frame_cases(meta):
+        if not name.startswith(("G1_", "G2_", "G5_")):
+            continue
+        info, gray, payload = case_inputs(arrays, meta, name)
+        delta, n_ac = info["delta"], info["n_ac"]
+        seg = orc.bits_to_str(payload) or None
+        g, stego, used = op(gray, "embed", delta, seg, num_ac_coeffs_to_use=n_ac)
+        assert used == info["used"] and isinstance(used, int), name
+        assert g is not gray and np.array_equal(g, gray) and sha(stego) == info["stego_sha256"], name
+        for src, tag in ((stego, "ext_stego"), (gray, "ext_cover")):
+            out = op(src, "extract", delta, num_ac_coeffs_to_use=n_ac)
+            assert isinstance(out, str) and len(out) == info[tag + "_len"], name
+            assert out == orc.bits_to_str(golden_bits(arrays, name, tag, info[tag + "_len"])), (name, tag)
+        ran += 1
+    assert ran >= 8
+    with pytest.raises(ValueError, match=meta["bad_rank_error"]):
+        op(np.zeros((8, 8, 4), np.uint8), "extract", 8)
+    assert op(np.zeros((16, 16), np.uint8), "nonsense", 8) is None
+
+
+def test_experiments_library_reproduces_the_golden_vectors(golden):
+    """lib/variants/libsvsdct_exp.so (same sources, -DSVS_EXPERIMENTS: knobs + measurement hooks) is what the counter-based
+    tests and tools/ab_bench.py load - it has to be the reference itself too."""
+    arrays, meta = golden
+    with using_library(experiments_library()):
+        for mode in ("guarded", "exact"):
+            for name in single_frame_cases(meta):
+                info, gray, payload = case_inputs(arrays, meta, name)
+                stego, used = batch.embed_frames(gray, info["delta"], info["n_ac"], payload, mode=mode)
+                assert used == info["used"] and sha(stego[0]) == info["stego_sha256"], (mode, name)
+                packed, n_bits = batch.extract_frames(stego[0], info["delta"], info["n_ac"], mode=mode)
+                assert n_bits == info["ext_stego_len"], name
+                assert np.array_equal(packed, arrays[f"{name}/ext_stego"][:packed.size]), (mode, name)
+
+
+def test_default_mode_launches_the_streaming_kernel(tmp_path):
+    """what the drop-in operator and the video pipelines run by default IS the streaming kernel bench.py
+    measures.  Checked where the kernels can be told apart - the experiments library's replay counter: embed_kernel adds the
+    blocks it redid exactly (flat blocks under zero bits are always among them), embed_exact_kernel never touches it."""
+    import config_and_setup as cs
+    from svsdct.pipeline import FramePipeline
+    exp = experiments_library()
+    d_cnt = _Dev(8)
+
+    def counted(fn):
+        native.check(exp.svs_memset(d_cnt.ptr, 0, 8, None), "memset")
+        native.check(exp.svs_stream_synchronize(None), "sync")
+        exp.svs_guard_counter_set(d_cnt.ptr)
+        try:
+            with using_library(exp):
+                fn()
+        finally:
+            exp.svs_guard_counter_set(None)
+        return int(d_cnt.get(8, np.uint64)[0])
+
+    flat = np.full((64, 128), 128, np.uint8)
+    for n_ac in (3, 10):
+        zeros = "0" * batch.capacity_bits(1, 64, 128, n_ac)
+        assert counted(lambda: cs.proses_frame_qim_dct(flat, "embed", 8, zeros, num_ac_coeffs_to_use=n_ac)) == 128   # every block
+        assert counted(lambda: batch.embed_frames(flat, 8, n_ac, np.zeros(len(zeros), np.uint8))) == 128
+        assert counted(lambda: batch.embed_frames(flat, 8, n_ac, np.zeros(len(zeros), np.uint8), mode="exact")) == 0
+
+        def through_pipeline():
+            with FramePipeline(64, 128, 2, 8, n_ac, depth=1) as pipe:          # mode unspecified, as a caller would
+                assert pipe.mode == batch.DEFAULT_MODE == "guarded"
+                pipe.set_payload(np.zeros(2 * len(zeros), np.uint8))
+                pipe.input(0)[:] = 128
+                pipe.submit_embed(0, 2, 0)
+                pipe.embed_result(0)
+        assert counted(through_pipeline) == 256
+    assert batch.host_level_mode() == "guarded"
+
+
+def test_string_payload_entry_points_equal_the_packed_ones():
+    """svs_embed_str / svs_extract_str take and return the reference operator's own payload type - '0'/'1' strings
+    (config_and_setup.py:106-109,173-174) - and convert on the device.  Same frames, counts and bits as the packed entry
+    points for every budget (none, "", one character, mid-block, capacity, the whole remaining payload of a long clip), odd
+    character counts (the 32-character packing tail), n = 0 / delta <= 0 with a non-empty payload (every block round-tripped),
+    several frames, and sizes that cross the staging ring's slot (1.3 M characters)."""
+    rng = np.random.default_rng(8)
+    for (f, h, w, n_ac, delta) in ((1, 64, 96, 10, 20), (3, 40, 72, 3, 8), (1, 24, 40, 0, 8), (1, 24, 40, 4, 0), (1, 24, 40, 4, -3),
+                                   (2, 16, 16, 63, 4), (1, 2160, 3840, 10, 20), (1, 2160, 3840, 63, 8)):
+        cover = synth.synthetic_frames(f, h, w, seed=h + n_ac)
+        cap = batch.capacity_bits(f, h, w, n_ac)
+        for n_chars in sorted({0, 1, 31, 33, max(cap // 2 - 3, 0), max(cap - 1, 0), cap, cap + 1000}):
+            bits = rng.integers(0, 2, n_chars).astype(np.uint8)
+            text = batch.bits_to_str(bits)
+            want, want_used = batch.embed_frames(cover, delta, n_ac, bits)
+            for payload in ((text,) if n_chars else (text, None)):
+                got, used = batch.embed_frames_str(cover, delta, n_ac, payload)
+                assert used == want_used and np.array_equal(got, want), (f, h, w, n_ac, delta, n_chars)
+        packed, n_bits = batch.extract_frames(want, delta, n_ac)
+        text = batch.extract_frames_str(want, delta, n_ac)
+        assert isinstance(text, str) and len(text) == n_bits == cap
+        assert text == batch.unpack_to_str(packed, n_bits)
+    with pytest.raises(ValueError):
+        batch.embed_frames_str(cover, 8, 3, "01\u20ac")                    # not a one-byte-per-character string

@@ -6,7 +6,7 @@ import os
 import numpy as np
 import pytest
 
-from testlib import REPO
+from testlib import REPO, experiments_library, using_library
 from svsdct import native
 
 pytestmark = pytest.mark.gpu
@@ -18,9 +18,7 @@ def test_cvt_pk_u8_f32_is_what_the_store_path_assumes():
     to nearest even - NOT truncation - so a non-integer must never reach it).  Check both on the device and record
     the raw behaviour."""
     native.ensure_device(0)
-    lib = native.load()
-    lib.svs_probe_cvt_pk_u8.restype = C.c_int
-    lib.svs_probe_cvt_pk_u8.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    lib = experiments_library()            # the probe is a measurement hook: experiments library only
     vals = np.concatenate([np.arange(-300, 600, dtype=np.float32),
                            np.array([-1.5, -0.5, -0.0, 0.49, 0.5, 0.51, 0.99999, 1.5, 2.5, 3.5, 127.5, 127.99999, 254.5,
                                      254.99, 255.5, 1e9, -1e9, np.inf, -np.inf], np.float32)])
@@ -36,38 +34,35 @@ def test_cvt_pk_u8_f32_is_what_the_store_path_assumes():
 
 
 def test_product_build_ignores_experiment_knobs(monkeypatch):
-    """no environment variable can reroute a kernel of the shipped library or touch the parity guarantee
-    of a flag.  The knobs that did in round 3 (SVS_GUARD_SCALE scaled the rigorous guard to zero, SVS_GUARDED_OFF /
-    SVS_GUARDED2_OFF / SVS_FAST_MAX_ROWS / SVS_EXACT_BPL / SVS_FIXED_N / SVS_EXTRACT_SHUFFLE picked other kernels) are compiled
-    only into lib/variants/libsvsdct_exp.so (-DSVS_EXPERIMENTS).  With all of them set, the default build's output is still the
-    oracle's, pixel for pixel and bit for bit, and the counter of exactly-redone blocks is what it is without them."""
-    import ctypes as C
-    import numpy as np
+    """No environment variable can reroute a kernel of the shipped library or touch the parity guarantee of a flag.  The knobs
+    that did in round 3 (SVS_GUARD_SCALE scaled the rigorous guard to zero, SVS_GUARDED_OFF / SVS_GUARDED2_OFF / SVS_EXACT_BPL /
+    SVS_FIXED_N / SVS_EXTRACT_SHUFFLE picked other kernels) are compiled only into lib/variants/libsvsdct_exp.so
+    (-DSVS_EXPERIMENTS).  With all of them set the product build's output is still the oracle's, pixel for pixel and bit for
+    bit - and the experiments library, where they ARE live, shows through its replay counter (a hook the product library does
+    not have any more) that they reroute: SVS_GUARDED_OFF sends every block to the lane-per-block kernel, which counts nothing."""
     from oracle import qim_dct_oracle as orc          # checker only
-    from svsdct import batch, native, synth
+    from svsdct import batch, synth
     native.ensure_device(0)
-    lib = native.load()
-    lib.svs_guard_counter_set.restype = C.c_int
-    lib.svs_guard_counter_set.argtypes = [C.c_void_p]
-    d_cnt = C.c_void_p()
-    native.check(lib.svs_malloc(C.byref(d_cnt), 8), "malloc")
 
-    def run():
+    def run(lib, d_cnt=None):
         out = []
         for (f, h, w, n_ac, delta) in ((2, 64, 136, 3, 8), (2, 64, 136, 10, 8), (1, 48, 96, 20, 8)):
             frames = synth.synthetic_frames(f, h, w, seed=n_ac)
             frames[0, :16, :64] = 77                                     # flat blocks: decided by the exact replay only
             payload = synth.synthetic_bits(batch.capacity_bits(f, h, w, n_ac), seed=n_ac)
-            native.check(lib.svs_memset(d_cnt, 0, 8, None), "memset")
-            native.check(lib.svs_stream_synchronize(None), "sync")
-            lib.svs_guard_counter_set(d_cnt)
+            redone = np.zeros(1, np.uint64)
+            if d_cnt is not None:
+                native.check(lib.svs_memset(d_cnt, 0, 8, None), "memset")
+                native.check(lib.svs_stream_synchronize(None), "sync")
+                lib.svs_guard_counter_set(d_cnt)
             try:
                 stego, used = batch.embed_frames(frames, delta, n_ac, payload, mode="guarded")
             finally:
-                lib.svs_guard_counter_set(None)
-            redone = np.zeros(1, np.uint64)
-            native.check(lib.svs_memcpy_d2h(redone.ctypes.data, d_cnt, 8, None), "d2h")
-            native.check(lib.svs_stream_synchronize(None), "sync")
+                if d_cnt is not None:
+                    lib.svs_guard_counter_set(None)
+            if d_cnt is not None:
+                native.check(lib.svs_memcpy_d2h(redone.ctypes.data, d_cnt, 8, None), "d2h")
+                native.check(lib.svs_stream_synchronize(None), "sync")
             ref, ref_used = orc.batch_embed(frames, delta, payload, n_ac)
             assert used == ref_used and np.array_equal(stego, ref), (n_ac, "stego differs from the oracle")
             packed, n_bits = batch.extract_frames(stego, delta, n_ac, mode="guarded")
@@ -75,12 +70,24 @@ def test_product_build_ignores_experiment_knobs(monkeypatch):
             out.append((int(redone[0]), stego.tobytes(), packed.tobytes()))
         return out
 
-    plain = run()
-    assert plain[0][0] > 0 and plain[1][0] > 0            # the guard really sends blocks to the exact replay
-    for name, value in (("SVS_GUARD_SCALE", "0"), ("SVS_GUARDED_OFF", "1"), ("SVS_GUARDED2_OFF", "1"), ("SVS_FAST_MAX_ROWS", "0"),
-                        ("SVS_EXACT_BPL", "2"), ("SVS_FIXED_N", "0"), ("SVS_EXTRACT_SHUFFLE", "1"), ("SVS_FAST_EXTRACT_U1", "1"),
-                        ("SVS_EMBED_BPL", "1"), ("SVS_EXTRACT_BPL", "2"), ("SVS_EMBED_XCD_CHUNK", "7"), ("SVS_EXTRACT_XCD_CHUNK", "5"),
-                        ("SVS_EMBED_WG_PER_CU", "2"), ("SVS_EXTRACT_WG_PER_CU", "2")):
+    knobs = (("SVS_GUARD_SCALE", "0"), ("SVS_GUARDED_OFF", "1"), ("SVS_GUARDED2_OFF", "1"), ("SVS_FAST_MAX_ROWS", "0"),
+             ("SVS_EXACT_BPL", "2"), ("SVS_FIXED_N", "0"), ("SVS_EXTRACT_SHUFFLE", "1"), ("SVS_FAST_EXTRACT_U1", "1"),
+             ("SVS_EMBED_BPL", "1"), ("SVS_EXTRACT_BPL", "2"), ("SVS_EMBED_XCD_CHUNK", "7"), ("SVS_EXTRACT_XCD_CHUNK", "5"),
+             ("SVS_EMBED_WG_PER_CU", "2"), ("SVS_EXTRACT_WG_PER_CU", "2"), ("SVS_STAGE_CHUNK_KB", "64"))
+    plain = run(native.load())
+    exp = experiments_library()
+    d_cnt = C.c_void_p()
+    native.check(exp.svs_malloc(C.byref(d_cnt), 8), "malloc")
+    with using_library(exp):
+        counted = run(exp, d_cnt)
+        assert [c[1:] for c in counted] == [p[1:] for p in plain]       # same sources: same bytes
+        assert counted[0][0] > 0 and counted[1][0] > 0 and counted[2][0] == 0   # the streaming kernels replay, n = 20 is the exact kernel
+        monkeypatch.setenv("SVS_GUARDED_OFF", "1")
+        rerouted = run(exp, d_cnt)
+        assert [c[0] for c in rerouted] == [0, 0, 0]                    # the knob is live HERE: every launch is the exact kernel
+        assert [c[1:] for c in rerouted] == [p[1:] for p in plain]      # ... whose bytes are the same
+        monkeypatch.delenv("SVS_GUARDED_OFF")
+    native.check(exp.svs_free(d_cnt), "free")
+    for name, value in knobs:
         monkeypatch.setenv(name, value)
-    assert run() == plain
-    native.check(lib.svs_free(d_cnt), "free")
+    assert run(native.load()) == plain

@@ -215,3 +215,27 @@ def test_float_domain_quantiser_step_equals_the_integer_form():
         c = np.ascontiguousarray(np.concatenate(parts))
         bit = rng.integers(0, 2, c.size).astype(np.uint8)
         assert lib.emu_qim_change_mismatches(c.ctypes.data, bit.ctypes.data, c.size, float(delta)) == 0, delta
+
+
+def test_launched_two_row_instantiations_equal_the_generic_one():
+    """the kernel launches embed_block_guarded2<QM, 10, true> at n = 10 (compile-time n, truncated inverse, stego
+    bytes written in place, undecided blocks left half-written and rebuilt from the parked rows) and <QM, 0, true> for the
+    other n = 8..15 with a general delta - instantiations the CPU tier never ran.  hostemu now dispatches exactly what
+    launch_embed does (exact = 4); exact = 5 forces the generic <QM, 0, false>.  Same bytes, same undecided blocks, and the
+    oracle's frame, on every content class, for power-of-two, general and float32-unrepresentable delta, full and partial budgets."""
+    h, w = 136, 240
+    covers = structured_covers(h, w)
+    covers["noise"] = synth.synthetic_frames(1, h, w, seed=77, lo=0, span=256)[0]
+    rng = np.random.default_rng(10)
+    for n_ac, delta in ((10, 8), (10, 20), (10, 0.3), (10, 7.5), (8, 20), (15, 3), (12, 1 / 3), (10, 4096)):
+        cap = (h // 8) * (w // 8) * n_ac
+        for name, cover in covers.items():
+            for n_bits in (cap, cap - n_ac - 3):
+                bits = rng.integers(0, 2, n_bits).astype(np.uint8) if name != "flat_128" else np.zeros(n_bits, np.uint8)
+                ra, rb = [], []
+                a, ua = emu_embed(cover, delta, n_ac, bits, exact=4, replayed=ra)
+                b, ub = emu_embed(cover, delta, n_ac, bits, exact=5, replayed=rb)
+                assert ua == ub and ra == rb and np.array_equal(a, b), (name, n_ac, delta, n_bits)
+                _, ref, ref_used = orc.frame_embed(cover, delta, bits, n_ac)
+                assert ua == ref_used and np.array_equal(a[0], ref), (name, n_ac, delta, n_bits)
+    assert ra[0] > 0

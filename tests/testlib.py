@@ -11,6 +11,51 @@ from svsdct import synth
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PKG_DIR = os.path.join(REPO, "secure-video-steganography-using-ecc-and-dct_amd")
 CSRC = os.path.join(PKG_DIR, "csrc")
+EXP_LIB_PATH = os.path.join(PKG_DIR, "lib", "variants", "libsvsdct_exp.so")
+
+# measurement hooks: exported by the EXPERIMENTS library only (csrc/svs_capi.hip, -DSVS_EXPERIMENTS)
+EXPERIMENT_HOOKS = {
+    "svs_guard_counter_set": (ctypes.c_int, [ctypes.c_void_p]),
+    "svs_ref_copy_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int, ctypes.c_void_p]),
+    "svs_ref_read_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p]),
+    "svs_probe_cvt_pk_u8": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]),
+}
+_exp_lib = None
+
+
+def experiments_library():
+    """lib/variants/libsvsdct_exp.so with every prototype of the product ABI plus the measurement hooks attached.  Built by
+    __graft_entry__.build(); the same kernel sources as the product library, so it has to pass the golden vectors itself
+    (tests/test_gpu_parity.py::test_experiments_library_reproduces_the_golden_vectors)."""
+    global _exp_lib
+    if _exp_lib is None:
+        from svsdct import native
+        if not os.path.exists(EXP_LIB_PATH):
+            raise RuntimeError(f"{EXP_LIB_PATH} is missing: run `python __graft_entry__.py` (make -C csrc exp)")
+        lib = ctypes.CDLL(EXP_LIB_PATH)
+        for name, (res, args) in {**native.SIGNATURES, **EXPERIMENT_HOOKS}.items():
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = res, args
+        _exp_lib = lib
+    return _exp_lib
+
+
+class using_library:
+    """`with using_library(experiments_library()):` - svsdct.batch / native route their calls to that library inside the block"""
+
+    def __init__(self, lib):
+        self.lib = lib
+
+    def __enter__(self):
+        from svsdct import native
+        self.saved, native._lib = native._lib, self.lib
+        return self.lib
+
+    def __exit__(self, *exc):
+        from svsdct import native
+        native._lib = self.saved
+        return False
+
 
 def natural_like(h, w, seed):
     """A frame with what real video has and uniform noise lacks: flat black bars, saturated highlights, smooth gradients,
