@@ -21,7 +21,8 @@
  *     chunks over the upload and the download stream of a per-thread staging context (upload of
  *     chunk k+1 beside the download of chunk k: the link is full duplex), nothing is allocated per call once the context has grown to the
  *     largest call, and a page-locked caller buffer (svs_host_alloc) is the DMA's own
- *     source / target - pageable memory goes through the context's pinned rings.
+ *     source / target - pageable memory goes through the HIP runtime's staging (uploads at
+ *     the same rate, downloads at about half of it: prefer page-locked OUTPUT buffers).
  *   - frames are gray uint8 planes, H and W multiples of 8 (the reference's callers crop:
  *     embed_process.py:94,113; extract_process.py:34,62), laid out [frame][row][col] with byte
  *     pitches given in svs_planes.
@@ -112,8 +113,8 @@ int svs_init(int device);
 /* Name of the architecture the device reports, e.g. "gfx950". */
 int svs_device_arch(int device, char *buf, size_t buf_len);
 /* Releases the CALLING THREAD's staging context of the host-pointer entry points (svs_embed, svs_extract, svs_embed_bgr,
- * svs_extract_bgr): two streams, grow-only device buffers as large as the largest call the thread has made, two rings of
- * pinned staging slots.  A thread's context is also released when the thread exits; calling any host-pointer entry point
+ * svs_extract_bgr, svs_embed_str, svs_extract_str): two streams and grow-only device buffers as large as the largest call the
+ * thread has made.  A thread's context is also released when the thread exits; calling any host-pointer entry point
  * afterwards simply builds a new one.  The *_dev entry points keep nothing. */
 int svs_shutdown(void);
 

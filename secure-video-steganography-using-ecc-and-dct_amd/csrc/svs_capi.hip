@@ -93,7 +93,7 @@ int make_geometry(const svs_planes *p, int n_ac, svs::Geometry *g, uint64_t *tot
     g->total_blocks = (uint32_t)total;
     g->n_ac = (uint32_t)clamp_ac(n_ac);
     g->xcd_chunk = 0;
-    g->pad = 0;
+    g->row_tiles = 0;
     g->row_pitch = p->row_pitch;
     g->frame_pitch = p->frame_pitch;
     *total_blocks = total;
@@ -174,11 +174,39 @@ unsigned long long *g_guard_counter = nullptr;
 // has 29 696 B): only the experiments library's occupancy-cap knob uses it
 constexpr uint32_t kEmbedLds = (SVS_WG / 64) * (SVS_GUARD_CAP * sizeof(svs::GuardEntry) + 8 * SVS_GUARD_TILE * sizeof(float));
 
+// block-row aligned tiles of embed_kernel (svs_device.hpp lane_block): -> Geometry::row_tiles and the grid size
+uint32_t row_tile_word(uint32_t wb, uint32_t bpl, uint64_t total_blocks, uint32_t *grid) {
+    const uint32_t lpr = wb / bpl;                                  // lanes a block row needs
+    const uint64_t brows = total_blocks / wb;
+    if (lpr == 0 || lpr > 0xffffu) return 0;
+    if (lpr <= SVS_WG) {
+        uint32_t rpw = SVS_WG / lpr;
+        if (rpw > 255) rpw = 255;
+        *grid = (uint32_t)((brows + rpw - 1) / rpw);
+        return lpr | (rpw << 16) | (1u << 24);
+    }
+    const uint32_t parts = (lpr + SVS_WG - 1) / SVS_WG, lpp = (lpr + parts - 1) / parts;
+    if (parts > 255 || brows * parts >= (1ull << 31)) return 0;
+    *grid = (uint32_t)(brows * parts);
+    return lpp | (1u << 16) | (parts << 24);
+}
+
+#ifndef SVS_EMBED_ROW_TILES
+#define SVS_EMBED_ROW_TILES 0      // block-row aligned tiles for the one-row embed kernel (experiment knob SVS_EMBED_ROW_TILES)
+#endif
 template <int QM, int BPL>
-int launch_embed(int rows, uint64_t total, hipStream_t st, const uint8_t *gray, uint8_t *stego, const svs::Geometry &g,
+int launch_embed(int rows, uint64_t total, hipStream_t st, const uint8_t *gray, uint8_t *stego, const svs::Geometry &g_in,
                  const svs::QimParams &qp, const uint32_t *bits, uint64_t bit_offset, uint64_t n_bits,
                  uint32_t n_words) {
-    const dim3 grid((uint32_t)((total + SVS_WG * BPL - 1) / (SVS_WG * BPL)));
+    svs::Geometry g = g_in;
+    uint32_t blocks = (uint32_t)((total + SVS_WG * BPL - 1) / (SVS_WG * BPL));
+    const uint32_t want_rt = knob("SVS_EMBED_ROW_TILES", SVS_EMBED_ROW_TILES);
+    if ((want_rt & (uint32_t)rows) != 0) {        // bit 0: the one-row kernel, bit 1: the two-row kernel
+        uint32_t rt_grid = 0;
+        const uint32_t word = row_tile_word(g.by_wb.div, BPL, total, &rt_grid);
+        if (word) { g.row_tiles = word; blocks = rt_grid; }
+    }
+    const dim3 grid(blocks);
     // (the occupancy cap is an experiments knob; the two-row kernel's parked form has 29 696 B of static LDS, the others kEmbedLds)
     const uint32_t lds_pad = lds_pad_for(knob("SVS_EMBED_WG_PER_CU", embed_wg_per_cu(rows, BPL)),
                                          rows == 2 && QM != svs::QM_POW2 ? 29696u : kEmbedLds);
@@ -342,8 +370,8 @@ struct DevBuf {  // RAII (measurement hooks of the experiments library)
 // Staging context of the HOST-pointer entry points (svs_embed / svs_extract / svs_embed_bgr / svs_extract_bgr).
 // What the reference's per-frame call sites hit (embed_process.py:117-121, extract_process.py:64-68: NumPy arrays in, NumPy
 // arrays out), so it has to run at the rate of the PCIe link, not of hipMalloc:
-//   * one context per HOST THREAD (thread_local): two non-blocking streams, grow-only device buffers, grow-only rings of
-//     pinned staging slots.  Nothing is allocated or freed per call once the buffers have grown to the largest call seen;
+//   * one context per HOST THREAD (thread_local): two non-blocking streams and grow-only device buffers.  Nothing is
+//     allocated or freed per call once the buffers have grown to the largest call seen;
 //     svs_shutdown() (or the thread's exit) releases them.  No state carries RESULTS from one call to the next - a call
 //     leaves nothing behind that a later call reads - and two host threads never share a context, so the entry points stay
 //     re-entrant and thread-safe.
@@ -354,20 +382,17 @@ struct DevBuf {  // RAII (measurement hooks of the experiments library)
 //     all three download, and the batch moves at the SERIAL rate of the link, 26.6 instead of 40+ Gpixel/s,
 //     profiles/r05_pcie_rate.txt.)  The payload is uploaded once; every chunk indexes it by bit offset.
 //   * a host buffer that is page-locked (svs_host_alloc, hipHostMalloc, hipHostRegister) is the source / target of the DMA
-//     itself; pageable memory goes through the pinned rings (memcpy of slot k+1 beside the DMA of slot k).
+//     itself; pageable memory goes through the runtime's staging (uploads at the same rate, downloads at about half of it:
+//     hand the library page-locked OUTPUT buffers - svsdct/hostmem.py does).
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int kStageStreams = 2;      // st[0] = up (H2D copies + kernels), st[1] = down (D2H copies)
-constexpr int kRingSlots = 4;
 constexpr int kChunkEvents = 32;      // "kernel of chunk k done" events, reused round-robin (a stream wait captures the
                                       // event's record at the time of the call, so re-recording one later is safe)
-#ifndef SVS_STAGE_SLOT_BYTES
-#define SVS_STAGE_SLOT_BYTES (4u << 20)      // bytes per pinned ring slot
-#endif
 #ifndef SVS_STAGE_CHUNK_BYTES
-#define SVS_STAGE_CHUNK_BYTES (4u << 20)     // largest chunk of frames
+#define SVS_STAGE_CHUNK_BYTES (8u << 20)     // largest chunk of frames
 #endif
-#ifndef SVS_STAGE_OWN_RING
-#define SVS_STAGE_OWN_RING 1                 // pageable host memory: 1 = through the context's pinned rings, 0 = the runtime's own staging
+#ifndef SVS_STAGE_CHUNK_MIN
+#define SVS_STAGE_CHUNK_MIN (4u << 20)       // smallest (a batch below twice this travels in one piece)
 #endif
 
 struct Grow {   // grow-only device buffer
@@ -375,26 +400,12 @@ struct Grow {   // grow-only device buffer
     size_t cap = 0;
 };
 
-struct PendingOut {   // a D2H slot whose bytes still have to be copied to the caller's pageable buffer
-    void *dst = nullptr;
-    size_t bytes = 0;
-};
-
-struct Ring {
-    void *slot[kRingSlots] = {nullptr, nullptr, nullptr, nullptr};
-    hipEvent_t done[kRingSlots] = {nullptr, nullptr, nullptr, nullptr};
-    bool busy[kRingSlots] = {false, false, false, false};
-    PendingOut out[kRingSlots];
-    uint32_t next = 0;
-};
-
 struct HostStage {
     int device = -1;
     hipStream_t st[kStageStreams] = {nullptr, nullptr};
     hipEvent_t chunk_done[kChunkEvents] = {};
     uint32_t next_event = 0;
-    Grow frames, second, third, bits;   // frames (in place) / BGR in; BGR out; gray reference; payload or extracted bits
-    Ring up, down;
+    Grow frames, second, third, bits;   // frames (in place) / BGR in; BGR out; gray reference or ASCII payload; packed payload / bits
     ~HostStage() { release(); }
 
     void release() {
@@ -404,12 +415,6 @@ struct HostStage {
         for (auto &s : st) if (s) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); s = nullptr; }
         for (auto &e : chunk_done) if (e) { (void)hipEventDestroy(e); e = nullptr; }
         for (Grow *g : {&frames, &second, &third, &bits}) { if (g->p) (void)hipFree(g->p); g->p = nullptr; g->cap = 0; }
-        for (Ring *r : {&up, &down})
-            for (int k = 0; k < kRingSlots; ++k) {
-                if (r->slot[k]) (void)hipHostFree(r->slot[k]);
-                if (r->done[k]) (void)hipEventDestroy(r->done[k]);
-                r->slot[k] = nullptr; r->done[k] = nullptr; r->busy[k] = false; r->out[k] = PendingOut{};
-            }
         if (switched) (void)hipSetDevice(cur);
         (void)hipGetLastError();
         device = -1;
@@ -442,89 +447,30 @@ int stage_reserve(Grow &g, size_t bytes) {
     return SVS_OK;
 }
 
-int ring_ready(Ring &r) {
-    if (r.slot[0]) return SVS_OK;
-    for (int k = 0; k < kRingSlots; ++k) {
-        SVS_HIP(hipHostMalloc(&r.slot[k], SVS_STAGE_SLOT_BYTES, hipHostMallocDefault));
-        SVS_HIP(hipEventCreateWithFlags(&r.done[k], hipEventDisableTiming));
-    }
-    return SVS_OK;
-}
-
-// is [p, p + bytes) page-locked memory the DMA engines can address?
-bool host_is_pinned(const void *p, size_t bytes) {
-    if (!p || bytes == 0) return false;
-    auto one = [](const void *q) {
-        hipPointerAttribute_t a;
-        if (hipPointerGetAttributes(&a, q) != hipSuccess) { (void)hipGetLastError(); return false; }
-        return a.type == hipMemoryTypeHost;
-    };
-    return one(p) && one(static_cast<const uint8_t *>(p) + bytes - 1);
-}
-
-// host -> device on `st`; returns once the source bytes have been read or belong to a pinned buffer the caller keeps alive
-// until the stream is synchronised
-int stage_h2d(HostStage &c, hipStream_t st, void *d_dst, const void *h_src, size_t bytes, bool pinned) {
+// host -> device on `st`.  Page-locked source: the DMA reads it (the caller keeps it alive until the stream is synchronised,
+// which every entry point does before it returns).  Pageable source: the runtime's own staging - hipMemcpyAsync then returns
+// when the bytes have been read.  (Round 5 measured a staging ring of the context's own - memcpy into pinned slots beside
+// the DMA - against it: 9.7 vs 6.3 ms per 265 MB upload, 0.39 vs 0.34 ms per 4K frame; the runtime pins the caller's pages
+// in place and moves them at the rate of page-locked memory.  profiles/r05_pcie_rate.txt.)
+int stage_h2d(hipStream_t st, void *d_dst, const void *h_src, size_t bytes) {
     if (bytes == 0) return SVS_OK;
-    if (pinned || !SVS_STAGE_OWN_RING) {
-        SVS_HIP(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, st));
-        return SVS_OK;
-    }
-    if (int rc = ring_ready(c.up)) return rc;
-    Ring &r = c.up;
-    for (size_t off = 0; off < bytes; off += SVS_STAGE_SLOT_BYTES) {
-        const size_t len = bytes - off < SVS_STAGE_SLOT_BYTES ? bytes - off : (size_t)SVS_STAGE_SLOT_BYTES;
-        const uint32_t k = r.next++ % kRingSlots;
-        if (r.busy[k]) { SVS_HIP(hipEventSynchronize(r.done[k])); r.busy[k] = false; }
-        memcpy(r.slot[k], static_cast<const uint8_t *>(h_src) + off, len);
-        SVS_HIP(hipMemcpyAsync(static_cast<uint8_t *>(d_dst) + off, r.slot[k], len, hipMemcpyHostToDevice, st));
-        SVS_HIP(hipEventRecord(r.done[k], st));
-        r.busy[k] = true;
-    }
+    SVS_HIP(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, st));
     return SVS_OK;
 }
 
-int ring_retire(Ring &r, uint32_t k) {   // finish slot k of the download ring: wait for its DMA, hand the bytes to the caller
-    if (!r.busy[k]) return SVS_OK;
-    SVS_HIP(hipEventSynchronize(r.done[k]));
-    if (r.out[k].dst) memcpy(r.out[k].dst, r.slot[k], r.out[k].bytes);
-    r.out[k] = PendingOut{};
-    r.busy[k] = false;
-    return SVS_OK;
-}
-
-// device -> host on `st`; pageable targets are complete only after stage_finish()
-int stage_d2h(HostStage &c, hipStream_t st, void *h_dst, const void *d_src, size_t bytes, bool pinned) {
+// device -> host on `st`; complete after stage_finish()
+int stage_d2h(hipStream_t st, void *h_dst, const void *d_src, size_t bytes) {
     if (bytes == 0) return SVS_OK;
-    if (pinned || !SVS_STAGE_OWN_RING) {
-        SVS_HIP(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, st));
-        return SVS_OK;
-    }
-    if (int rc = ring_ready(c.down)) return rc;
-    Ring &r = c.down;
-    for (size_t off = 0; off < bytes; off += SVS_STAGE_SLOT_BYTES) {
-        const size_t len = bytes - off < SVS_STAGE_SLOT_BYTES ? bytes - off : (size_t)SVS_STAGE_SLOT_BYTES;
-        const uint32_t k = r.next++ % kRingSlots;
-        if (int rc = ring_retire(r, k)) return rc;
-        SVS_HIP(hipMemcpyAsync(r.slot[k], static_cast<const uint8_t *>(d_src) + off, len, hipMemcpyDeviceToHost, st));
-        SVS_HIP(hipEventRecord(r.done[k], st));
-        r.out[k] = PendingOut{static_cast<uint8_t *>(h_dst) + off, len};
-        r.busy[k] = true;
-    }
+    SVS_HIP(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, st));
     return SVS_OK;
 }
 
-// end of a call: every stream drained, every pageable target filled, the rings idle.  Also the error path: a call that fails
-// half way must not leave a DMA in flight into the caller's buffers or a slot marked busy.
+// end of a call: both streams drained (every copy into the caller's buffers has landed).  Also the error path: a call that
+// fails half way must not leave a DMA in flight into the caller's buffers.
 int stage_finish(HostStage &c) {
     int rc = SVS_OK;
-    for (uint32_t i = 0; i < kRingSlots; ++i) {   // oldest first
-        const uint32_t k = (c.down.next + i) % kRingSlots;
-        if (int e = ring_retire(c.down, k)) rc = rc ? rc : e;
-    }
     for (auto &s : c.st)
         if (s && hipStreamSynchronize(s) != hipSuccess) rc = rc ? rc : fail(SVS_ERR_HIP, "hipStreamSynchronize failed: %s", hipGetErrorString(hipGetLastError()));
-    for (int k = 0; k < kRingSlots; ++k) { c.up.busy[k] = false; c.down.busy[k] = false; c.down.out[k] = PendingOut{}; }
     return rc;
 }
 
@@ -572,14 +518,16 @@ void for_each_chunk(int32_t n_frames, int32_t H, size_t row_bytes, size_t target
     }
 }
 
-// chunk size of a batch of `total` bytes: an eighth of it, so that a single frame is pipelined as well (one 4K frame = eight
-// bands of 1 MB: nine chunk times instead of sixteen), within [512 KB, 4 MB] - below, the fixed cost of a DMA shows; above,
-// nothing is gained (sweep in profiles/r05_pcie_rate.txt; the experiments library's SVS_STAGE_CHUNK_KB overrides it)
+// chunk size of a batch of `total` bytes: an eighth of it within [4 MB, 8 MB].  A chunk costs about 33 us of host time (two
+// copies, the kernel launch, the event and its wait), so small chunks lose more than their overlap wins: one 4K frame is
+// fastest as two bands of 4 MB (0.34 ms against 0.38 in one piece and 0.49 in eight), a 1080p frame in one piece, a batch of
+// 32 4K frames in chunks of 8 MB (6.2 ms against 9.5 in one piece) - tools/stage_chunk_sweep.py, profiles/r05_pcie_rate.txt.
+// The experiments library's SVS_STAGE_CHUNK_KB overrides the rule.
 size_t stage_chunk_bytes(uint64_t total) {
     const uint32_t forced = knob("SVS_STAGE_CHUNK_KB", 0);
     if (forced) return (size_t)forced << 10;
     const uint64_t eighth = total / 8;
-    return (size_t)(eighth < (512u << 10) ? (512u << 10) : (eighth > SVS_STAGE_CHUNK_BYTES ? SVS_STAGE_CHUNK_BYTES : eighth));
+    return (size_t)(eighth < SVS_STAGE_CHUNK_MIN ? SVS_STAGE_CHUNK_MIN : (eighth > SVS_STAGE_CHUNK_BYTES ? SVS_STAGE_CHUNK_BYTES : eighth));
 }
 
 template <int QM, bool EXACT>
@@ -645,6 +593,15 @@ int svs_device_arch(int device, char *buf, size_t buf_len) {
 int svs_malloc(void **dev_ptr, size_t bytes) {
     if (!dev_ptr) return fail(SVS_ERR_INVALID_ARG, "dev_ptr is NULL");
     *dev_ptr = nullptr;
+#if defined(SVS_EXPERIMENTS)
+    // experiment: physically contiguous device memory (hipDeviceMallocContiguous), falling back to a plain allocation
+    if (knob("SVS_MALLOC_CONTIG", 0) != 0 && bytes >= ((size_t)2 << 20)) {
+        if (hipExtMallocWithFlags(dev_ptr, bytes, hipDeviceMallocContiguous) == hipSuccess && *dev_ptr) return SVS_OK;
+        (void)hipGetLastError();
+        *dev_ptr = nullptr;
+        if (knob("SVS_MALLOC_CONTIG", 0) == 2) return fail(SVS_ERR_HIP, "contiguous allocation of %zu bytes failed", bytes);
+    }
+#endif
     SVS_HIP(hipMalloc(dev_ptr, bytes ? bytes : 4));
     return SVS_OK;
 }
@@ -891,7 +848,7 @@ static int stage_payload(HostStage &c, const uint8_t *bits_packed, uint64_t bit_
     if (bit_bytes) {
         // the kernels read whole dwords: the tail behind the last payload byte must be defined (zero)
         SVS_HIP(hipMemsetAsync(static_cast<uint8_t *>(c.bits.p) + (bit_alloc - 8), 0, 8, c.st[0]));
-        if (int rc = stage_h2d(c, c.st[0], c.bits.p, bits_packed + first_byte, bit_bytes, host_is_pinned(bits_packed + first_byte, bit_bytes)))
+        if (int rc = stage_h2d(c.st[0], c.bits.p, bits_packed + first_byte, bit_bytes))
             return rc;
     } else {
         SVS_HIP(hipMemsetAsync(c.bits.p, 0, bit_alloc, c.st[0]));
@@ -907,7 +864,7 @@ static int stage_payload_ascii(HostStage &c, const char *bits_ascii, uint64_t us
     SVS_HIP(hipMemsetAsync(static_cast<uint8_t *>(c.bits.p) + 4 * words, 0, 8, c.st[0]));
     if (use == 0) return SVS_OK;
     if (int rc = stage_reserve(c.third, use + 32)) return rc;
-    if (int rc = stage_h2d(c, c.st[0], c.third.p, bits_ascii, use, host_is_pinned(bits_ascii, use))) return rc;
+    if (int rc = stage_h2d(c.st[0], c.third.p, bits_ascii, use)) return rc;
     const uint32_t blocks = (uint32_t)((words + 255) / 256 < 2048 ? (words + 255) / 256 : 2048);
     hipLaunchKernelGGL(svs::ascii_to_packed_kernel, dim3(blocks), dim3(256), 0, c.st[0], static_cast<const uint8_t *>(c.third.p), use,
                        static_cast<uint32_t *>(c.bits.p), words);
@@ -955,7 +912,6 @@ static int embed_host(const uint8_t *gray, uint8_t *stego, const svs_planes *pla
     // a non-empty payload that cannot be embedded (delta <= 0, n_ac = 0) must still reach the kernel as "non-empty": every
     // block is then round-tripped, as in the reference
     const uint64_t pass_bits = use ? use : (n_bits ? 1 : 0);
-    const bool in_pinned = host_is_pinned(gray, span), out_pinned = host_is_pinned(stego, span);
     const int32_t H = planes->height, W = planes->width;
     const int64_t rp = planes->row_pitch, fp = planes->frame_pitch;
     const bool rows_packed = rp == W, frames_packed = rows_packed && fp == (int64_t)H * W;
@@ -968,7 +924,7 @@ static int embed_host(const uint8_t *gray, uint8_t *stego, const svs_planes *pla
         if (rc) return;
         const int64_t off = (int64_t)ch.f0 * fp + (int64_t)ch.r0 * rp;
         const size_t bytes = ch.nf == 1 ? (size_t)(ch.rows - 1) * rp + W : (size_t)(ch.nf - 1) * fp + (size_t)(H - 1) * rp + W;
-        if ((rc = stage_h2d(c, up, d + off, gray + off, bytes, in_pinned))) return;
+        if ((rc = stage_h2d(up, d + off, gray + off, bytes))) return;
         const svs_planes sub{ch.nf, ch.rows, W, 0, rp, ch.nf == 1 ? (int64_t)ch.rows * rp : fp};
         const uint64_t g0 = (uint64_t)ch.f0 * bpf + (uint64_t)(ch.r0 / 8) * wb;
         uint64_t done = 0;
@@ -979,11 +935,11 @@ static int embed_host(const uint8_t *gray, uint8_t *stego, const svs_planes *pla
         if ((rc = stage_handoff(c))) return;
         // back: pixel bytes only (padding in the caller's stego buffer is left alone)
         if (frames_packed || (rows_packed && ch.nf == 1)) {
-            rc = stage_d2h(c, st, stego + off, d + off, ch.nf == 1 ? (size_t)ch.rows * W : (size_t)ch.nf * H * W, out_pinned);
+            rc = stage_d2h(st, stego + off, d + off, ch.nf == 1 ? (size_t)ch.rows * W : (size_t)ch.nf * H * W);
         } else {
             for (int32_t f = 0; f < ch.nf && !rc; ++f) {
                 const int64_t o = off + (int64_t)f * fp;
-                if (rows_packed) rc = stage_d2h(c, st, stego + o, d + o, (size_t)ch.rows * W, out_pinned);
+                if (rows_packed) rc = stage_d2h(st, stego + o, d + o, (size_t)ch.rows * W);
                 else if (hipMemcpy2DAsync(stego + o, (size_t)rp, d + o, (size_t)rp, (size_t)W, (size_t)ch.rows, hipMemcpyDeviceToHost, st) != hipSuccess)
                     rc = fail(SVS_ERR_HIP, "hipMemcpy2DAsync failed: %s", hipGetErrorString(hipGetLastError()));
             }
@@ -1026,15 +982,14 @@ int svs_extract(const uint8_t *gray, const svs_planes *planes, double delta, int
     StageGuard guard(ctx);
     if (int rc = stage_reserve(c.frames, span)) return guard.done(rc);
     if (int rc = stage_reserve(c.bits, bytes + 8)) return guard.done(rc);
-    // the download is n_ac / 512 of the upload: one stream, one kernel over the batch; the upload is chunked only through
-    // the pinned ring when the caller's frames are pageable
+    // the download is n_ac / 512 of the upload: nothing to overlap - one stream, one copy, one kernel over the batch
     hipStream_t st = c.st[0];
-    if (int rc = stage_h2d(c, st, c.frames.p, gray, span, host_is_pinned(gray, span))) return guard.done(rc);
+    if (int rc = stage_h2d(st, c.frames.p, gray, span)) return guard.done(rc);
     uint64_t got = 0;
     if (int rc = svs_extract_dev(static_cast<const uint8_t *>(c.frames.p), planes, delta, n_ac, static_cast<uint8_t *>(c.bits.p),
                                  bytes + 8, flags, &got, st))
         return guard.done(rc);
-    if (int rc = stage_d2h(c, st, bits_packed_out, c.bits.p, bytes, host_is_pinned(bits_packed_out, bytes))) return guard.done(rc);
+    if (int rc = stage_d2h(st, bits_packed_out, c.bits.p, bytes)) return guard.done(rc);
     if (int rc = guard.done(SVS_OK)) return rc;
     if (n_bits_out) *n_bits_out = got;
     return SVS_OK;
@@ -1061,7 +1016,7 @@ int svs_extract_str(const uint8_t *gray, const svs_planes *planes, double delta,
     if (int rc = stage_reserve(c.bits, bytes + 8)) return guard.done(rc);
     if (int rc = stage_reserve(c.third, 8 * bytes + 8)) return guard.done(rc);
     hipStream_t st = c.st[0];
-    if (int rc = stage_h2d(c, st, c.frames.p, gray, span, host_is_pinned(gray, span))) return guard.done(rc);
+    if (int rc = stage_h2d(st, c.frames.p, gray, span)) return guard.done(rc);
     uint64_t got = 0;
     if (int rc = svs_extract_dev(static_cast<const uint8_t *>(c.frames.p), planes, delta, n_ac, static_cast<uint8_t *>(c.bits.p),
                                  bytes + 8, flags, &got, st))
@@ -1070,7 +1025,7 @@ int svs_extract_str(const uint8_t *gray, const svs_planes *planes, double delta,
     hipLaunchKernelGGL(svs::packed_to_ascii_kernel, dim3(blocks), dim3(256), 0, st, static_cast<const uint8_t *>(c.bits.p), bytes,
                        static_cast<svs::u32x2 *>(c.third.p));
     if (hipGetLastError() != hipSuccess) return guard.done(fail(SVS_ERR_HIP, "packed_to_ascii_kernel launch failed"));
-    if (int rc = stage_d2h(c, st, bits_ascii_out, c.third.p, cap, host_is_pinned(bits_ascii_out, cap))) return guard.done(rc);
+    if (int rc = stage_d2h(st, bits_ascii_out, c.third.p, cap)) return guard.done(rc);
     if (int rc = guard.done(SVS_OK)) return rc;
     if (n_bits_out) *n_bits_out = got;
     return SVS_OK;
@@ -1291,8 +1246,6 @@ int svs_embed_bgr(const uint8_t *bgr, uint8_t *bgr_out, uint8_t *gray_ref_out, c
     uint64_t rebased = 0;
     if (int rc = stage_payload(c, bits_packed, bit_offset, use, &rebased)) return guard.done(rc);
     const uint64_t pass_bits = use ? use : (n_bits ? 1 : 0);   // see svs_embed
-    const bool in_pinned = host_is_pinned(bgr, 3 * px), out_pinned = host_is_pinned(bgr_out, 3 * px),
-               ref_pinned = gray_ref_out && host_is_pinned(gray_ref_out, px);
     const uint64_t wb = (uint64_t)W / 8, bpf = wb * ((uint64_t)H / 8);
     const int64_t rp3 = 3 * (int64_t)W;
     uint8_t *d_in = static_cast<uint8_t *>(c.frames.p), *d_out = static_cast<uint8_t *>(c.second.p),
@@ -1303,7 +1256,7 @@ int svs_embed_bgr(const uint8_t *bgr, uint8_t *bgr_out, uint8_t *gray_ref_out, c
     for_each_chunk(planes->n_frames, H, (size_t)rp3, stage_chunk_bytes(3 * px), [&](const Chunk &ch) {   // frames are tightly packed: every chunk is one run of bytes
         if (rc) return;
         const uint64_t first_px = ((uint64_t)ch.f0 * H + ch.r0) * W, n_px = (uint64_t)ch.nf * ch.rows * W;
-        if ((rc = stage_h2d(c, up, d_in + 3 * first_px, bgr + 3 * first_px, 3 * n_px, in_pinned))) return;
+        if ((rc = stage_h2d(up, d_in + 3 * first_px, bgr + 3 * first_px, 3 * n_px))) return;
         const svs_planes sub{ch.nf, ch.rows, W, 0, W, (int64_t)ch.rows * W};
         const uint64_t g0 = (uint64_t)ch.f0 * bpf + (uint64_t)(ch.r0 / 8) * wb;
         uint64_t done = 0;
@@ -1313,8 +1266,8 @@ int svs_embed_bgr(const uint8_t *bgr, uint8_t *bgr_out, uint8_t *gray_ref_out, c
             return;
         done_total += done;
         if ((rc = stage_handoff(c))) return;
-        if ((rc = stage_d2h(c, st, bgr_out + 3 * first_px, d_out + 3 * first_px, 3 * n_px, out_pinned))) return;
-        if (d_ref) rc = stage_d2h(c, st, gray_ref_out + first_px, d_ref + first_px, n_px, ref_pinned);
+        if ((rc = stage_d2h(st, bgr_out + 3 * first_px, d_out + 3 * first_px, 3 * n_px))) return;
+        if (d_ref) rc = stage_d2h(st, gray_ref_out + first_px, d_ref + first_px, n_px);
     });
     rc = guard.done(rc);
     if (rc) return rc;
@@ -1344,13 +1297,13 @@ int svs_extract_bgr(const uint8_t *bgr, const svs_planes *planes, const uint32_t
     if (int rc = stage_reserve(c.frames, 3 * px)) return guard.done(rc);
     if (int rc = stage_reserve(c.bits, bytes + 8)) return guard.done(rc);
     hipStream_t st = c.st[0];
-    if (int rc = stage_h2d(c, st, c.frames.p, bgr, 3 * px, host_is_pinned(bgr, 3 * px))) return guard.done(rc);
+    if (int rc = stage_h2d(st, c.frames.p, bgr, 3 * px)) return guard.done(rc);
     const int64_t rp = 3 * (int64_t)planes->width, fp = rp * planes->height;
     uint64_t got = 0;
     if (int rc = svs_extract_bgr_dev(static_cast<const uint8_t *>(c.frames.p), rp, fp, planes, weights, delta, n_ac,
                                      static_cast<uint8_t *>(c.bits.p), bytes + 8, &got, st))
         return guard.done(rc);
-    if (int rc = stage_d2h(c, st, bits_packed_out, c.bits.p, bytes, host_is_pinned(bits_packed_out, bytes))) return guard.done(rc);
+    if (int rc = stage_d2h(st, bits_packed_out, c.bits.p, bytes)) return guard.done(rc);
     if (int rc = guard.done(SVS_OK)) return rc;
     if (n_bits_out) *n_bits_out = got;
     return SVS_OK;

@@ -1,0 +1,88 @@
+#!/usr/bin/env python3
+"""Round 5: the embed launch on SEVERAL buffer placements x SEVERAL kernel configurations, one process, sustained bursts.
+Placement decides 1.50 vs 1.65+ ms per 600 x 4K (tools/placement_probe.py) through DRAM write-credit stalls
+(tools/placement_counters.py); is any store policy / tile map less sensitive to it?
+  base      product library: non-temporal loads, write-through (sc1) stores, one contiguous eighth of the batch per XCD
+  map0/32   experiments library, identity tile map / runs of 32 tiles per XCD
+  rowtile   experiments library, block-row aligned tiles (a workgroup reads and writes ONE contiguous stretch: eight full pixel rows)
+  nosc1     non-temporal stores instead of write-through          (make -C csrc placement-variants)
+  plain     default-policy loads and stores
+  copy      a plain copy kernel with the embed kernel's access policy (nt loads, sc1 stores), same bytes"""
+import argparse, ctypes as C, os, sys
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(REPO, "secure-video-steganography-using-ecc-and-dct_amd")
+sys.path.insert(0, PKG); sys.path.insert(0, os.path.join(REPO, "tests"))
+import numpy as np
+import torch
+from svsdct import batch, native
+from svsdct.native import Planes
+from testlib import EXPERIMENT_HOOKS
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--pairs", type=int, default=6); ap.add_argument("--burst", type=int, default=8); ap.add_argument("--rounds", type=int, default=3)
+ap.add_argument("--n-ac", type=int, default=3)
+a = ap.parse_args()
+
+
+def load(name, hooks=False):
+    lib = C.CDLL(os.path.join(PKG, "lib", name))
+    for nm, (res, args) in {**native.SIGNATURES, **(EXPERIMENT_HOOKS if hooks else {})}.items():
+        fn = getattr(lib, nm); fn.restype, fn.argtypes = res, args
+    return lib
+
+
+base = load("libsvsdct.so")
+exp = load("variants/libsvsdct_exp.so", hooks=True)
+configs = [("base", base, {}), ("map0", exp, {"SVS_EMBED_XCD_CHUNK": "0"}), ("map32", exp, {"SVS_EMBED_XCD_CHUNK": "32"}),
+           ("rowtile", exp, {"SVS_EMBED_ROW_TILES": "3"}), ("rowt+m0", exp, {"SVS_EMBED_ROW_TILES": "3", "SVS_EMBED_XCD_CHUNK": "0"}),
+           ("rowt+m32", exp, {"SVS_EMBED_ROW_TILES": "3", "SVS_EMBED_XCD_CHUNK": "32"})]
+for v in ("nosc1", "plain"):
+    p = os.path.join(PKG, "lib", "variants", f"libsvsdct_{v}.so")
+    if os.path.exists(p):
+        configs.append((v, load(f"variants/libsvsdct_{v}.so"), {}))
+torch.cuda.set_device(0)
+assert base.svs_init(0) == 0
+F, H, W, n, delta = 600, 2160, 3840, a.n_ac, 8.0
+planes = Planes.contiguous(F, H, W)
+size, cap = F * H * W, batch.capacity_bits(F, H, W, n)
+st = torch.cuda.current_stream().cuda_stream
+pay = torch.zeros((cap + 7) // 8 + 16, dtype=torch.uint8, device="cuda")
+assert base.svs_fill_bits_dev(pay.data_ptr(), cap, 1, 0, st) == 0
+pairs = []
+for k in range(a.pairs):
+    g, s = C.c_void_p(), C.c_void_p()
+    assert base.svs_malloc(C.byref(g), size) == 0 and base.svs_malloc(C.byref(s), size) == 0
+    assert base.svs_fill_synthetic_dev(g, C.byref(planes), 20250620, 0, 16, 224, st) == 0
+    pairs.append((g, s))
+done = C.c_uint64()
+
+
+def burst(lib, env, g, s, copy=False):
+    for k, v in env.items():
+        os.environ[k] = v
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(a.burst + 1)]
+    ev[0].record()
+    for i in range(a.burst):
+        if copy:
+            assert exp.svs_ref_copy_dev(g, s, size, 3, st) == 0
+        else:
+            assert lib.svs_embed_dev(g, s, C.byref(planes), delta, n, pay.data_ptr(), 0, cap, 2, C.byref(done), st) == 0
+        ev[i + 1].record()
+    torch.cuda.synchronize()
+    for k in env:
+        os.environ.pop(k)
+    return [ev[i].elapsed_time(ev[i + 1]) for i in range(1, a.burst)]      # the first launch of a burst warms up
+
+
+res = {}
+for r in range(a.rounds):
+    for pi, (g, s) in enumerate(pairs):
+        for name, lib, env in configs:
+            res.setdefault((pi, name), []).extend(burst(lib, env, g, s))
+        res.setdefault((pi, "copy"), []).extend(burst(exp, {}, g, s, copy=True))
+names = [c[0] for c in configs] + ["copy"]
+print(f"# 600 x 4K, n = {n}, delta = 8: median ms per embed launch in sustained bursts, {a.pairs} placements (hipMalloc pairs) x configurations")
+print("pair   " + "  ".join(f"{nm:>8s}" for nm in names))
+for pi in range(a.pairs):
+    print(f"{pi:4d}   " + "  ".join(f"{np.median(res[(pi, nm)]):8.4f}" for nm in names))
+print("spread " + "  ".join(f"{max(np.median(res[(pi, nm)]) for pi in range(a.pairs)) / min(np.median(res[(pi, nm)]) for pi in range(a.pairs)):8.3f}" for nm in names))
