@@ -56,41 +56,31 @@ extern "C" {
 #define SVS_ERR_CAPACITY (-4)     /* an output buffer is too small */
 
 /* `flags` of the embed / extract entry points.  EVERY value gives the reference's stego pixels and extracted bits, bit for
- * bit; the flags choose between two kernel families.
- * The streaming embed kernel (csrc/svs_device.hpp; n_ac <= 15, 0.25 <= delta <= 4096): every block goes HBM -> registers ->
- * HBM once, computed with a cheap sparse transform; a block whose result the float32 round-trip noise of the reference's
- * own transform could decide (config_and_setup.py:166-171 transforms every block forth and back and truncates: x - 1e-5
- * becomes x - 1) is "undecided" and is redone INSIDE the kernel with the pocketfft-identical arithmetic (eight lanes per
- * block, LDS worklist private to the wave) - no second launch, no scratch memory, no state kept between calls: every entry
- * point is re-entrant and thread-safe.  The library reads no environment variable.
- *   0                  the same launches as SVS_EXACT_GUARDED: bit-identical to the reference.  (Rounds 1-3 had a separate
- *                      contract-level "FAST" embed arithmetic for n_ac >= 8 behind this value - FMA-factored forward
- *                      transform, per-pixel grid test skipped for blocks that looked generic.  Every review found structured
- *                      content on which the shortcut broke the PSNR contract - last: smooth ramps under a zero-heavy
- *                      payload, +0.68 dB - and with the test on every pixel it was no faster than the bit-identical
- *                      kernels, so it is gone.)  Extraction: bits identical to the reference's for ANY input frame
- *                      (n_ac <= 7: pocketfft-identical transform; n_ac >= 8: FMA-factored transform, a block with a
- *                      quantiser input within a proven error bound of a rounding tie is recomputed with the
- *                      pocketfft-identical one).
- *   SVS_EXACT_POCKETFFT  every float32 operation of scipy.fftpack.dct/idct(norm='ortho') (pocketfft) is replayed in
- *                      order, on all 64 coefficients of every block, one lane per block: stego pixels, tie decisions
- *                      and the reference's round-trip artefacts are bit-identical to the reference.  About 5x the
- *                      arithmetic of the streaming kernel: VALU-bound (0.42 of the HBM roofline).  The yardstick the
- *                      other kernels are tested against, and what every mode runs for n_ac >= 16.
- *   SVS_EXACT_GUARDED  the same bit-identical result at streaming speed: the kernel computes the payload coefficients
- *                      exactly as pocketfft does (every quantiser decision is the reference's), predicts each stego
- *                      pixel from the sparse inverse of the coefficient changes, and keeps the prediction only where a
- *                      RIGOROUS per-block bound on the reference's round-trip noise (tools/guard_bound.py: running
- *                      error analysis of every pocketfft operation; BETA = u (17.0 mean + 31.05 ||block - mean||_2 +
- *                      KD (1.5 delta + 0.01)) + 2^-20, KD = 19.6 for n_ac <= 7, 54.8 for n_ac <= 15, and at least 2^-14
- *                      for n_ac = 8..15) proves the
- *                      truncation cannot differ; the blocks it cannot decide are redone exactly inside the launch
- *                      (n_ac <= 7: 8 tests per block, 0.05 - 1.7 % of the blocks, 12.5 % of flat ones at n = 3;
- *                      n_ac = 8..15: 64 tests with position-dependent bounds, 1.5 - 13 %).  Applies to n_ac <= 15 and
- *                      0.25 <= delta <= 4096; other calls run the SVS_EXACT_POCKETFFT kernels, so the flag is always
- *                      safe to pass and always bit-identical.  Extraction with this flag runs the same kernels as
- *                      flags = 0 inside that delta range, the pocketfft-identical kernels outside it.  Default of the
- *                      drop-in operator and video pipelines. */
+ * bit; the flags only choose between two kernel families.
+ *   0 / SVS_EXACT_GUARDED  (identical in behaviour; SVS_EXACT_GUARDED is kept as a named value for ABI compatibility and is
+ *                      what the Python layer passes by default.)  Embedding with n_ac <= 15 and 0.25 <= delta <= 4096 runs the
+ *                      STREAMING kernel (csrc/svs_device.hpp): every block goes HBM -> registers -> HBM once; the kernel
+ *                      computes the payload coefficients exactly as pocketfft does (every quantiser decision is the
+ *                      reference's), predicts each stego pixel from the sparse inverse of the coefficient changes, and keeps
+ *                      the prediction only where a RIGOROUS per-block bound on the reference's own float32 round-trip noise
+ *                      (tools/guard_bound.py: running error analysis of every pocketfft operation; BETA = u (17.0 mean +
+ *                      31.05 ||block - mean||_2 + KD (1.5 delta + 0.01)) + 2^-20, KD = 19.6 for n_ac <= 7, 54.8 for
+ *                      n_ac <= 15, and at least 2^-14 for n_ac = 8..15) proves the truncation cannot differ
+ *                      (config_and_setup.py:166-171 transforms every block forth and back and truncates: x - 1e-5 becomes
+ *                      x - 1).  The blocks it cannot decide (n_ac <= 7: 8 tests per block, 0.05 - 1.7 % of the blocks, 12.5 %
+ *                      of flat ones at n = 3; n_ac = 8..15: 64 tests with position-dependent bounds, 1.5 - 13 %) are redone
+ *                      INSIDE the launch with the pocketfft-identical arithmetic (eight lanes per block, LDS worklist
+ *                      private to the wave) - no second launch, no scratch memory.  Every other embed call (n_ac >= 16, delta
+ *                      outside the range) runs the SVS_EXACT_POCKETFFT kernel.  Extraction: n_ac <= 7 the
+ *                      pocketfft-identical forward transform; n_ac >= 8 an FMA-factored transform, a block with a quantiser
+ *                      input within a proven error bound of a rounding tie being recomputed with the pocketfft-identical
+ *                      one - the reference's bits for ANY input frame.
+ *   SVS_EXACT_POCKETFFT  every float32 operation of scipy.fftpack.dct/idct(norm='ortho') (pocketfft) is replayed in order, on
+ *                      all 64 coefficients of every block, one lane per block.  About 5x the arithmetic of the streaming
+ *                      kernel: VALU-bound (0.33 - 0.42 of the HBM roofline).  The yardstick the other kernels are tested
+ *                      against.
+ * The *_dev entry points keep no state at all; the host-pointer entry points keep a per-thread staging context (below).
+ * Every entry point is re-entrant and thread-safe.  The library reads no environment variable. */
 #define SVS_EXACT_POCKETFFT 1u
 #define SVS_EXACT_GUARDED 2u
 
@@ -164,12 +154,16 @@ int svs_embed(const uint8_t *gray, uint8_t *stego, const svs_planes *planes,
               const uint8_t *bits_packed, uint64_t bit_offset, uint64_t n_bits,
               uint32_t flags, uint64_t *n_embedded);
 
-/* The same call with the payload in the reference operator's own form: `bit_payload_segment`, a string of '0' / '1'
- * characters (config_and_setup.py:106-109,124-126; one character per bit, no terminator needed).  n_chars characters are
- * available, min(n_chars, capacity) are read - a frame loop may hand over the whole remaining payload as the reference does
- * (embed_process.py:116-121) - and are packed on the device.  n_chars > 0 with nothing embeddable (delta <= 0, n_ac <= 0)
- * still round-trips every block, n_chars = 0 (or NULL) copies the frames, as in the reference. */
-int svs_embed_str(const uint8_t *gray, uint8_t *stego, const svs_planes *planes,
+/* The same call in the reference operator's own types (config_and_setup.py:106-109,172): the payload is `bit_payload_segment`,
+ * a string of '0' / '1' characters (one character per bit, no terminator needed), and the operator's first return value - the
+ * gray frame before embedding, as an array of its own (:113-114) - is produced as well.
+ *   bits_ascii, n_chars : n_chars characters are available, min(n_chars, capacity) are read - a frame loop may hand over the
+ *                         whole remaining payload as the reference does (embed_process.py:116-121) - and are packed on the
+ *                         device.  n_chars > 0 with nothing embeddable (delta <= 0, n_ac <= 0) still round-trips every block,
+ *                         n_chars = 0 (or NULL) copies the frames, as in the reference (:124-126).
+ *   gray_ref_out        : NULL, or a buffer of the planes' geometry that receives a copy of `gray` (pixel bytes only).  The
+ *                         calling thread makes the copy while the GPU works, so it costs the call nothing. */
+int svs_embed_str(const uint8_t *gray, uint8_t *gray_ref_out, uint8_t *stego, const svs_planes *planes,
                   double delta, int n_ac, const char *bits_ascii, uint64_t n_chars,
                   uint32_t flags, uint64_t *n_embedded);
 

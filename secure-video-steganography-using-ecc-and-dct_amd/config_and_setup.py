@@ -67,18 +67,6 @@ def bitstream_ke_int(bitstream_nilai: str, jumlah_bit_diharapkan=None) -> int:
 # ------------------------------------------------------------------------------------------
 # the frame operator (reference :106-174) - GPU
 # ------------------------------------------------------------------------------------------
-_COPY_POOL = None
-
-
-def _copy_pool():
-    """one helper thread for the frame copy that runs beside the GPU call (created on first use)"""
-    global _COPY_POOL
-    if _COPY_POOL is None:
-        from concurrent.futures import ThreadPoolExecutor
-        _COPY_POOL = ThreadPoolExecutor(max_workers=1, thread_name_prefix="svs-frame-copy")
-    return _COPY_POOL
-
-
 def _bgr_to_gray(frame_bgr: np.ndarray) -> np.ndarray:
     """cv2.cvtColor(frame, COLOR_BGR2GRAY) (reference :112).  Uses OpenCV when it is installed so
     that the gray plane is the reference's; otherwise OpenCV 4's fixed-point BT.601 table
@@ -114,26 +102,16 @@ def proses_frame_qim_dct(frame_bgr_input, mode, delta,
         raise ValueError("Format frame input tidak didukung.")
     src = np.ascontiguousarray(gray, np.uint8)          # what the kernels read; the caller's own memory when it can be
     if mode == "embed":
-        # The first return value is the gray frame BEFORE embedding as an array of its own (:113-114,172).  For a 2-D input
-        # that is a copy of the caller's frame; the library reads pageable memory at the rate of the link, so the upload goes
-        # straight from the caller's frame and the copy is made beside it (a helper thread for frames of a megabyte and more:
-        # NumPy's copy and the ctypes call both release the GIL) - 0.1 ms of a 4K call that would otherwise be serial.
-        pending = None
-        if src is frame or np.shares_memory(src, frame):
-            if src.nbytes >= (1 << 20):
-                pending = _copy_pool().submit(src.copy)
-            else:
-                gray_ref = src.copy()
-        else:
-            gray_ref = src
         # the operator receives the whole remaining payload as a '0'/'1' string and reads at most the capacity; the library
-        # takes the string as it is (svs_embed_str).  None / "" = nothing to embed: the frame is copied (:124-126)
-        try:
+        # takes the string as it is (svs_embed_str).  None / "" = nothing to embed: the frame is copied (:124-126).
+        # The first return value is the gray frame BEFORE embedding as an array of its own (:113-114,172): for a 2-D input a
+        # copy of the caller's frame, which the library makes while the GPU works - the upload reads the caller's own memory
+        fresh = not (src is frame or np.may_share_memory(src, frame))
+        if fresh:
             stego, used = _batch.embed_frames_str(src, delta, num_ac_coeffs_to_use, bit_payload_segment)
-        finally:
-            if pending is not None:
-                gray_ref = pending.result()
-        return gray_ref, stego[0], used
+            return src, stego[0], used
+        gray_ref, stego, used = _batch.embed_frames_str(src, delta, num_ac_coeffs_to_use, bit_payload_segment, want_gray=True)
+        return gray_ref[0], stego[0], used
     if mode == "extract":
         return _batch.extract_frames_str(src, delta, num_ac_coeffs_to_use)
     return None

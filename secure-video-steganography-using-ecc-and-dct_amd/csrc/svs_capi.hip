@@ -93,7 +93,7 @@ int make_geometry(const svs_planes *p, int n_ac, svs::Geometry *g, uint64_t *tot
     g->total_blocks = (uint32_t)total;
     g->n_ac = (uint32_t)clamp_ac(n_ac);
     g->xcd_chunk = 0;
-    g->row_tiles = 0;
+    g->pad = 0;
     g->row_pitch = p->row_pitch;
     g->frame_pitch = p->frame_pitch;
     *total_blocks = total;
@@ -174,39 +174,11 @@ unsigned long long *g_guard_counter = nullptr;
 // has 29 696 B): only the experiments library's occupancy-cap knob uses it
 constexpr uint32_t kEmbedLds = (SVS_WG / 64) * (SVS_GUARD_CAP * sizeof(svs::GuardEntry) + 8 * SVS_GUARD_TILE * sizeof(float));
 
-// block-row aligned tiles of embed_kernel (svs_device.hpp lane_block): -> Geometry::row_tiles and the grid size
-uint32_t row_tile_word(uint32_t wb, uint32_t bpl, uint64_t total_blocks, uint32_t *grid) {
-    const uint32_t lpr = wb / bpl;                                  // lanes a block row needs
-    const uint64_t brows = total_blocks / wb;
-    if (lpr == 0 || lpr > 0xffffu) return 0;
-    if (lpr <= SVS_WG) {
-        uint32_t rpw = SVS_WG / lpr;
-        if (rpw > 255) rpw = 255;
-        *grid = (uint32_t)((brows + rpw - 1) / rpw);
-        return lpr | (rpw << 16) | (1u << 24);
-    }
-    const uint32_t parts = (lpr + SVS_WG - 1) / SVS_WG, lpp = (lpr + parts - 1) / parts;
-    if (parts > 255 || brows * parts >= (1ull << 31)) return 0;
-    *grid = (uint32_t)(brows * parts);
-    return lpp | (1u << 16) | (parts << 24);
-}
-
-#ifndef SVS_EMBED_ROW_TILES
-#define SVS_EMBED_ROW_TILES 0      // block-row aligned tiles for the one-row embed kernel (experiment knob SVS_EMBED_ROW_TILES)
-#endif
 template <int QM, int BPL>
-int launch_embed(int rows, uint64_t total, hipStream_t st, const uint8_t *gray, uint8_t *stego, const svs::Geometry &g_in,
+int launch_embed(int rows, uint64_t total, hipStream_t st, const uint8_t *gray, uint8_t *stego, const svs::Geometry &g,
                  const svs::QimParams &qp, const uint32_t *bits, uint64_t bit_offset, uint64_t n_bits,
                  uint32_t n_words) {
-    svs::Geometry g = g_in;
-    uint32_t blocks = (uint32_t)((total + SVS_WG * BPL - 1) / (SVS_WG * BPL));
-    const uint32_t want_rt = knob("SVS_EMBED_ROW_TILES", SVS_EMBED_ROW_TILES);
-    if ((want_rt & (uint32_t)rows) != 0) {        // bit 0: the one-row kernel, bit 1: the two-row kernel
-        uint32_t rt_grid = 0;
-        const uint32_t word = row_tile_word(g.by_wb.div, BPL, total, &rt_grid);
-        if (word) { g.row_tiles = word; blocks = rt_grid; }
-    }
-    const dim3 grid(blocks);
+    const dim3 grid((uint32_t)((total + SVS_WG * BPL - 1) / (SVS_WG * BPL)));
     // (the occupancy cap is an experiments knob; the two-row kernel's parked form has 29 696 B of static LDS, the others kEmbedLds)
     const uint32_t lds_pad = lds_pad_for(knob("SVS_EMBED_WG_PER_CU", embed_wg_per_cu(rows, BPL)),
                                          rows == 2 && QM != svs::QM_POW2 ? 29696u : kEmbedLds);
@@ -882,7 +854,7 @@ static uint64_t chunk_budget(uint64_t pass_bits, uint64_t use, uint64_t g0, uint
 
 // svs_embed (payload = packed MSB-first bits, indexed by bit_offset) and svs_embed_str (payload = n_bits '0' / '1' characters,
 // bit_offset = 0) share everything but the way the payload reaches the device
-static int embed_host(const uint8_t *gray, uint8_t *stego, const svs_planes *planes, double delta, int n_ac,
+static int embed_host(const uint8_t *gray, uint8_t *stego, uint8_t *gray_ref_out, const svs_planes *planes, double delta, int n_ac,
                       const uint8_t *bits_packed, const char *bits_ascii, uint64_t bit_offset, uint64_t n_bits, uint32_t flags,
                       uint64_t *n_embedded) {
     svs::Geometry g;
@@ -919,7 +891,11 @@ static int embed_host(const uint8_t *gray, uint8_t *stego, const svs_planes *pla
     uint8_t *d = static_cast<uint8_t *>(c.frames.p);
     uint64_t done_total = 0;
     int rc = SVS_OK;
-    hipStream_t up = c.st[0], st = c.st[1];
+    // one chunk (a frame below 8 MB): everything in order on one stream - no event, no second stream
+    uint32_t n_chunks = 0;
+    for_each_chunk(planes->n_frames, H, (size_t)rp, stage_chunk_bytes(span), [&](const Chunk &) { ++n_chunks; });
+    const bool serial = n_chunks <= 1 || knob("SVS_STAGE_MODE", 0) == 2;
+    hipStream_t up = c.st[0], st = serial ? c.st[0] : c.st[1];
     for_each_chunk(planes->n_frames, H, (size_t)rp, stage_chunk_bytes(span), [&](const Chunk &ch) {
         if (rc) return;
         const int64_t off = (int64_t)ch.f0 * fp + (int64_t)ch.r0 * rp;
@@ -932,7 +908,7 @@ static int embed_host(const uint8_t *gray, uint8_t *stego, const svs_planes *pla
                                 rebased + (use ? g0 * (uint64_t)g.n_ac : 0), chunk_budget(pass_bits, use, g0, g.n_ac), flags, &done, up)))
             return;
         done_total += done;
-        if ((rc = stage_handoff(c))) return;
+        if (!serial && (rc = stage_handoff(c))) return;
         // back: pixel bytes only (padding in the caller's stego buffer is left alone)
         if (frames_packed || (rows_packed && ch.nf == 1)) {
             rc = stage_d2h(st, stego + off, d + off, ch.nf == 1 ? (size_t)ch.rows * W : (size_t)ch.nf * H * W);
@@ -945,6 +921,16 @@ static int embed_host(const uint8_t *gray, uint8_t *stego, const svs_planes *pla
             }
         }
     });
+    // the operator's first return value - the gray frames before embedding as arrays of their own (config_and_setup.py:113-114,
+    // 172) - is copied by the calling thread HERE, while the streams work: everything is enqueued, the thread would only wait
+    if (!rc && gray_ref_out && gray_ref_out != gray) {
+        if (frames_packed) {
+            memcpy(gray_ref_out, gray, span);
+        } else {
+            for (int32_t f = 0; f < planes->n_frames; ++f)
+                for (int32_t y = 0; y < H; ++y) memcpy(gray_ref_out + (int64_t)f * fp + (int64_t)y * rp, gray + (int64_t)f * fp + (int64_t)y * rp, (size_t)W);
+        }
+    }
     rc = guard.done(rc);
     if (rc) return rc;
     if (n_embedded) *n_embedded = done_total;
@@ -953,13 +939,14 @@ static int embed_host(const uint8_t *gray, uint8_t *stego, const svs_planes *pla
 
 int svs_embed(const uint8_t *gray, uint8_t *stego, const svs_planes *planes, double delta, int n_ac,
               const uint8_t *bits_packed, uint64_t bit_offset, uint64_t n_bits, uint32_t flags, uint64_t *n_embedded) {
-    return embed_host(gray, stego, planes, delta, n_ac, bits_packed, nullptr, bit_offset, n_bits, flags, n_embedded);
+    return embed_host(gray, stego, nullptr, planes, delta, n_ac, bits_packed, nullptr, bit_offset, n_bits, flags, n_embedded);
 }
 
-int svs_embed_str(const uint8_t *gray, uint8_t *stego, const svs_planes *planes, double delta, int n_ac,
+int svs_embed_str(const uint8_t *gray, uint8_t *gray_ref_out, uint8_t *stego, const svs_planes *planes, double delta, int n_ac,
                   const char *bits_ascii, uint64_t n_chars, uint32_t flags, uint64_t *n_embedded) {
     if (n_chars && !bits_ascii) return fail(SVS_ERR_INVALID_ARG, "bits pointer is NULL");
-    return embed_host(gray, stego, planes, delta, n_ac, nullptr, bits_ascii ? bits_ascii : "", 0, n_chars, flags, n_embedded);
+    if (gray_ref_out && (gray_ref_out == stego)) return fail(SVS_ERR_INVALID_ARG, "gray_ref_out must not be the stego buffer");
+    return embed_host(gray, stego, gray_ref_out, planes, delta, n_ac, nullptr, bits_ascii ? bits_ascii : "", 0, n_chars, flags, n_embedded);
 }
 
 int svs_extract(const uint8_t *gray, const svs_planes *planes, double delta, int n_ac, uint8_t *bits_packed_out,
@@ -1252,7 +1239,10 @@ int svs_embed_bgr(const uint8_t *bgr, uint8_t *bgr_out, uint8_t *gray_ref_out, c
             *d_ref = gray_ref_out ? static_cast<uint8_t *>(c.third.p) : nullptr;
     uint64_t done_total = 0;
     int rc = SVS_OK;
-    hipStream_t up = c.st[0], st = c.st[1];
+    uint32_t n_chunks = 0;
+    for_each_chunk(planes->n_frames, H, (size_t)rp3, stage_chunk_bytes(3 * px), [&](const Chunk &) { ++n_chunks; });
+    const bool serial = n_chunks <= 1 || knob("SVS_STAGE_MODE", 0) == 2;
+    hipStream_t up = c.st[0], st = serial ? c.st[0] : c.st[1];
     for_each_chunk(planes->n_frames, H, (size_t)rp3, stage_chunk_bytes(3 * px), [&](const Chunk &ch) {   // frames are tightly packed: every chunk is one run of bytes
         if (rc) return;
         const uint64_t first_px = ((uint64_t)ch.f0 * H + ch.r0) * W, n_px = (uint64_t)ch.nf * ch.rows * W;
@@ -1265,7 +1255,7 @@ int svs_embed_bgr(const uint8_t *bgr, uint8_t *bgr_out, uint8_t *gray_ref_out, c
                                     rebased + (use ? g0 * (uint64_t)g.n_ac : 0), chunk_budget(pass_bits, use, g0, g.n_ac), flags, &done, up)))
             return;
         done_total += done;
-        if ((rc = stage_handoff(c))) return;
+        if (!serial && (rc = stage_handoff(c))) return;
         if ((rc = stage_d2h(st, bgr_out + 3 * first_px, d_out + 3 * first_px, 3 * n_px))) return;
         if (d_ref) rc = stage_d2h(st, gray_ref_out + first_px, d_ref + first_px, n_px);
     });

@@ -26,8 +26,7 @@ struct Geometry {
     uint32_t total_blocks;  // n_frames * blocks per frame   (< 2^31)
     uint32_t n_ac;          // 1..63
     uint32_t xcd_chunk;     // tile_id() chunk (0 = identity)
-    uint32_t row_tiles;     // 0: a workgroup takes SVS_WG * BPL consecutive blocks.  Otherwise block-row aligned tiles (embed_kernel):
-                            // lanes per block-row part | block rows per workgroup << 16 | parts per block row << 24 (lane_block())
+    uint32_t pad;
     int64_t row_pitch;
     int64_t frame_pitch;
 };
@@ -65,36 +64,6 @@ __device__ __forceinline__ uint32_t tile_id(uint32_t chunk) {
     if (i >= full) return i;
     const uint32_t x = i % 8u, j = i / 8u;
     return (j / chunk) * span + x * chunk + (j % chunk);
-}
-
-// The lane's first block.  Default: workgroup `tile` takes blocks [tile * SVS_WG * BPL, + SVS_WG * BPL) in raster order - at 4K
-// (480 blocks per block row) a tile straddles two block rows and its eight row segments of 4 KB lie in two different
-// 30 KB stretches of the frame.  Block-row aligned tiles (g.row_tiles != 0): a workgroup takes whole block rows (or an
-// equal part of one when a block row has more than SVS_WG * BPL blocks), so what it reads and writes is ONE contiguous
-// stretch of memory - eight full pixel rows.  Some lanes stay idle (4K, two blocks per lane: 240 of 256 work).
-// -> false: the lane has no block
-template <int BPL>
-__device__ __forceinline__ bool lane_block(const Geometry &g, uint32_t &gblock) {
-    const uint32_t tile = tile_id(g.xcd_chunk);
-    if (g.row_tiles == 0) {
-        gblock = (tile * (uint32_t)SVS_WG + threadIdx.x) * BPL;
-        return gblock < g.total_blocks;
-    }
-    const uint32_t lpp = g.row_tiles & 0xffffu, rpw = (g.row_tiles >> 16) & 0xffu, parts = g.row_tiles >> 24;
-    const uint32_t wb = g.by_wb.div;
-    uint32_t brow, l;
-    if (parts > 1) {
-        brow = tile / parts;
-        l = (tile - brow * parts) * lpp + threadIdx.x;
-        if (threadIdx.x >= lpp || l * BPL >= wb) { gblock = 0; return false; }
-    } else {
-        const uint32_t r = threadIdx.x / lpp;
-        l = threadIdx.x - r * lpp;
-        brow = tile * rpw + r;
-        if (r >= rpw) { gblock = 0; return false; }
-    }
-    gblock = brow * wb + l * BPL;
-    return gblock < g.total_blocks;
 }
 
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
@@ -822,8 +791,10 @@ __global__ __launch_bounds__(SVS_WG, kEmbedMinWaves<U>) void embed_kernel(const 
         __syncthreads();   // at the very start: no wave has work in flight yet
     }
 #endif
-    uint32_t gblock;
-    const bool has_block = lane_block<BPL>(g, gblock);
+    // (Round 5 tried block-row aligned tiles - a workgroup reads and writes ONE contiguous stretch, eight full pixel rows, at
+    // the price of idle lanes - to bring the launch from the rate of a copy with this access pattern to that of a linear copy:
+    // 1.73 vs 1.64 ms per 600 x 4K at n = 3, 3.15 vs 2.63 at n = 10, slower on every placement: profiles/r05_ab_row_tiles.txt.)
+    const uint32_t gblock = (tile_id(g.xcd_chunk) * (uint32_t)SVS_WG + threadIdx.x) * BPL;
     const uint32_t n = g.n_ac;
     bool und_a = false, und_b = false, write = false;
     // n <= 15: the payload window of a block is its first word - kept in a register from phase 1, because re-reading it for
@@ -834,7 +805,7 @@ __global__ __launch_bounds__(SVS_WG, kEmbedMinWaves<U>) void embed_kernel(const 
     typename RowVec<BPL>::type v[8];
     uint32_t ax[8], ay[8], bx[8], by[8];
     int64_t off = 0;
-    if (has_block) {
+    if (gblock < g.total_blocks) {
         off = block_offset(gblock, g);
         load_rows<BPL>(gray + off, g.row_pitch, v);
 #pragma unroll

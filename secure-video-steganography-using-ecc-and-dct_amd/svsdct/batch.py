@@ -180,22 +180,26 @@ def _ascii_address(text: str):
     return addr, size.value
 
 
-def embed_frames_str(frames: np.ndarray, delta, n_ac, payload: str | None, device: int = 0, mode: str | None = None):
-    """`embed_frames` for a payload in the reference operator's own form, a '0'/'1' string (bit_payload_segment,
-    config_and_setup.py:106-109): at most the capacity is read from its front, the characters go to the device as they are
-    and are packed there (svs_embed_str).  None / "" = nothing to embed.  Returns (stego uint8 [F,H,W], n_embedded)."""
+def embed_frames_str(frames: np.ndarray, delta, n_ac, payload: str | None, device: int = 0, mode: str | None = None,
+                     want_gray: bool = False):
+    """`embed_frames` in the reference operator's own types (config_and_setup.py:106-109,172): the payload is a '0'/'1'
+    string (bit_payload_segment) of which at most the capacity is read from the front - the characters go to the device as
+    they are and are packed there (svs_embed_str); None / "" = nothing to embed.  want_gray: also return a copy of the input
+    frames as an array of its own, the operator's first return value - the library makes it while the GPU works.
+    Returns (stego uint8 [F,H,W], n_embedded) or (gray_copy, stego, n_embedded)."""
     lib = native.load()
     native.ensure_device(device)
     stack = _as_stack(frames)
     f, h, w = stack.shape
     addr, n_chars = _ascii_address(payload) if payload else (None, 0)
     stego = pinned_empty(stack.shape)
+    gray = np.empty_like(stack) if want_gray else None
     done = C.c_uint64(0)
     planes = Planes.contiguous(f, h, w)
-    rc = lib.svs_embed_str(stack.ctypes.data, stego.ctypes.data, C.byref(planes), float(delta), int(n_ac), addr, n_chars,
-                           mode_flags(mode), C.byref(done))
+    rc = lib.svs_embed_str(stack.ctypes.data, gray.ctypes.data if want_gray else None, stego.ctypes.data, C.byref(planes),
+                           float(delta), int(n_ac), addr, n_chars, mode_flags(mode), C.byref(done))
     native.check(rc, "svs_embed_str")
-    return stego, int(done.value)
+    return (gray, stego, int(done.value)) if want_gray else (stego, int(done.value))
 
 
 def extract_frames_str(frames: np.ndarray, delta, n_ac, device: int = 0, mode: str | None = None) -> str:

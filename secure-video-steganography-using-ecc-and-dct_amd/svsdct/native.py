@@ -65,7 +65,7 @@ SIGNATURES = {
     "svs_packed_bytes": (C.c_uint64, [C.c_uint64]),
     "svs_embed_dev": (C.c_int, [_u8p, _u8p, _PL, C.c_double, C.c_int, _u8p, C.c_uint64, C.c_uint64, C.c_uint32, _u64p, C.c_void_p]),
     "svs_embed": (C.c_int, [_u8p, _u8p, _PL, C.c_double, C.c_int, _u8p, C.c_uint64, C.c_uint64, C.c_uint32, _u64p]),
-    "svs_embed_str": (C.c_int, [_u8p, _u8p, _PL, C.c_double, C.c_int, C.c_void_p, C.c_uint64, C.c_uint32, _u64p]),
+    "svs_embed_str": (C.c_int, [_u8p, _u8p, _u8p, _PL, C.c_double, C.c_int, C.c_void_p, C.c_uint64, C.c_uint32, _u64p]),
     "svs_extract_str": (C.c_int, [_u8p, _PL, C.c_double, C.c_int, C.c_void_p, C.c_uint64, C.c_uint32, _u64p]),
     "svs_extract_dev": (C.c_int, [_u8p, _PL, C.c_double, C.c_int, _u8p, C.c_uint64, C.c_uint32, _u64p, C.c_void_p]),
     "svs_extract": (C.c_int, [_u8p, _PL, C.c_double, C.c_int, _u8p, C.c_uint64, C.c_uint32, _u64p]),

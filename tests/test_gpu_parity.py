@@ -1028,6 +1028,19 @@ def test_host_pointer_calls_chunked_staging_pitched_pinned_and_pageable(chunk_kb
                                  native.SVS_EXACT_GUARDED, C.byref(got_bits))
             assert rc == 0 and got_bits.value == cap
             assert np.array_equal(np.unpackbits(out, count=cap), orc.batch_extract_bits(want, delta, n_ac))
+    # the string form on the same pitched clip, with the operator's first return value: pixel bytes copied, padding left alone
+    text = batch.bits_to_str(bits[off:]).encode()
+    ref = np.full(f * fp, 0x5A, np.uint8)
+    dst[:] = 0xA5
+    rc = exp.svs_embed_str(src.ctypes.data, ref.ctypes.data, dst.ctypes.data, C.byref(planes), float(delta), n_ac, text, len(text),
+                           native.SVS_EXACT_GUARDED, C.byref(used))
+    assert rc == 0 and used.value == want_used
+    for k in range(f):
+        assert np.array_equal(dst[k * fp:k * fp + h * rp].reshape(h, rp)[:, :w], want[k])
+        assert np.array_equal(ref[k * fp:k * fp + h * rp].reshape(h, rp)[:, :w], cover[k])
+    assert (dst[mask] == 0xA5).all() and (ref[mask] == 0x5A).all()
+    assert exp.svs_embed_str(src.ctypes.data, dst.ctypes.data, dst.ctypes.data, C.byref(planes), float(delta), n_ac, text, len(text),
+                             native.SVS_EXACT_GUARDED, C.byref(used)) == native.SVS_ERR_INVALID_ARG
     assert span <= f * fp
     assert exp.svs_shutdown() == 0                                        # the thread's context goes; the next call rebuilds it
     stego, used = batch.embed_frames(cover, delta, n_ac, synth.synthetic_bits(cap, seed=1))
@@ -1179,6 +1192,10 @@ def test_string_payload_entry_points_equal_the_packed_ones():
             for payload in ((text,) if n_chars else (text, None)):
                 got, used = batch.embed_frames_str(cover, delta, n_ac, payload)
                 assert used == want_used and np.array_equal(got, want), (f, h, w, n_ac, delta, n_chars)
+            # with the operator's first return value: a copy of the input made by the library beside the GPU work
+            ref, got, used = batch.embed_frames_str(cover, delta, n_ac, text, want_gray=True)
+            assert used == want_used and np.array_equal(got, want) and np.array_equal(ref, cover)
+            assert not np.may_share_memory(ref, cover) and not np.may_share_memory(ref, got)
         packed, n_bits = batch.extract_frames(want, delta, n_ac)
         text = batch.extract_frames_str(want, delta, n_ac)
         assert isinstance(text, str) and len(text) == n_bits == cap

@@ -86,6 +86,8 @@ for r in range(a.rounds + 2):
 # every lane copies its block), (2) torch's contiguous device-to-device copy
 ceil = {"pattern_copy": [], "torch_copy": [], "copy16_nt": [], "copy_gridstride_nt": [], "copy_gridstride": [], "read_nt": [],
         "copy16_nt_sc1st": [], "copy16_nt_sc0sc1nt_st": [], "copy16_sc1ld_sc1st": []}
+# the plain copy / read kernels are measurement hooks: they live in the experiments library only (round 5)
+l0 = C.CDLL(os.path.join(REPO, "secure-video-steganography-using-ecc-and-dct_amd", "lib", "variants", "libsvsdct_exp.so"))
 l0.svs_ref_copy_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p]
 l0.svs_ref_read_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
 sink = torch.zeros(4096, dtype=torch.int32, device=dev)

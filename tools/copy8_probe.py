@@ -1,5 +1,7 @@
 import ctypes as C, os, sys, statistics
 sys.path.insert(0, os.path.join(os.getcwd(), "secure-video-steganography-using-ecc-and-dct_amd"))
+# the copy kernels are measurement hooks of the experiments library (round 5: the product library exports only its header)
+os.environ.setdefault("SVSDCT_LIB", os.path.join(os.getcwd(), "secure-video-steganography-using-ecc-and-dct_amd", "lib", "variants", "libsvsdct_exp.so"))
 import torch
 from svsdct import native
 lib = native.load(); native.ensure_device(0)

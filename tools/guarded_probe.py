@@ -6,6 +6,9 @@ Frames are 3840x2160 device-resident; times are HIP events on the launch stream,
 import argparse, ctypes as C, json, os, statistics, sys
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(REPO, "secure-video-steganography-using-ecc-and-dct_amd"))
+# the replay counter is a measurement hook of the experiments library (round 5: the product library exports only its header;
+# same kernel sources, so the times are the product's)
+os.environ.setdefault("SVSDCT_LIB", os.path.join(REPO, "secure-video-steganography-using-ecc-and-dct_amd", "lib", "variants", "libsvsdct_exp.so"))
 import torch
 from svsdct import batch, native
 from svsdct.native import Planes

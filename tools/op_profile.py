@@ -38,7 +38,9 @@ for (h, w) in ((2160, 3840), (1080, 1920)):
     print(f"_ascii_address(payload)                        {t(lambda: batch._ascii_address(payload)):.4f}")
     for name, s_, d_ in (("page-locked in, page-locked out", src_pin, dst_pin), ("pageable in,    page-locked out", frame, dst_pin),
                          ("pageable in,    pageable out   ", frame, dst_page)):
-        print(f"svs_embed_str raw, {name}  {t(lambda: lib.svs_embed_str(s_.ctypes.data, d_.ctypes.data, C.byref(planes), float(delta), n_ac, addr, nch, 2, C.byref(used))):.3f}")
+        print(f"svs_embed_str raw, {name}  {t(lambda: lib.svs_embed_str(s_.ctypes.data, None, d_.ctypes.data, C.byref(planes), float(delta), n_ac, addr, nch, 2, C.byref(used))):.3f}")
+    ref_page = np.empty_like(frame)
+    print(f"svs_embed_str raw + gray_ref_out, pageable in, page-locked out  {t(lambda: lib.svs_embed_str(frame.ctypes.data, ref_page.ctypes.data, dst_pin.ctypes.data, C.byref(planes), float(delta), n_ac, addr, nch, 2, C.byref(used))):.3f}")
     pk = batch.pack_bits(batch.str_to_bits(payload, cap))
     print(f"svs_embed raw (packed bits), page-locked both  {t(lambda: lib.svs_embed(src_pin.ctypes.data, dst_pin.ctypes.data, C.byref(planes), float(delta), n_ac, pk.ctypes.data, 0, cap, 2, C.byref(used))):.3f}")
     print(f"batch.embed_frames_str(pageable frame)         {t(lambda: batch.embed_frames_str(frame, delta, n_ac, payload)):.3f}")

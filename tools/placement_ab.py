@@ -4,7 +4,7 @@ Placement decides 1.50 vs 1.65+ ms per 600 x 4K (tools/placement_probe.py) throu
 (tools/placement_counters.py); is any store policy / tile map less sensitive to it?
   base      product library: non-temporal loads, write-through (sc1) stores, one contiguous eighth of the batch per XCD
   map0/32   experiments library, identity tile map / runs of 32 tiles per XCD
-  rowtile   experiments library, block-row aligned tiles (a workgroup reads and writes ONE contiguous stretch: eight full pixel rows)
+  (session r5e also ran block-row aligned tiles here - removed since: profiles/r05_ab_row_tiles.txt)
   nosc1     non-temporal stores instead of write-through          (make -C csrc placement-variants)
   plain     default-policy loads and stores
   copy      a plain copy kernel with the embed kernel's access policy (nt loads, sc1 stores), same bytes"""
@@ -33,9 +33,7 @@ def load(name, hooks=False):
 
 base = load("libsvsdct.so")
 exp = load("variants/libsvsdct_exp.so", hooks=True)
-configs = [("base", base, {}), ("map0", exp, {"SVS_EMBED_XCD_CHUNK": "0"}), ("map32", exp, {"SVS_EMBED_XCD_CHUNK": "32"}),
-           ("rowtile", exp, {"SVS_EMBED_ROW_TILES": "3"}), ("rowt+m0", exp, {"SVS_EMBED_ROW_TILES": "3", "SVS_EMBED_XCD_CHUNK": "0"}),
-           ("rowt+m32", exp, {"SVS_EMBED_ROW_TILES": "3", "SVS_EMBED_XCD_CHUNK": "32"})]
+configs = [("base", base, {}), ("map0", exp, {"SVS_EMBED_XCD_CHUNK": "0"}), ("map32", exp, {"SVS_EMBED_XCD_CHUNK": "32"})]
 for v in ("nosc1", "plain"):
     p = os.path.join(PKG, "lib", "variants", f"libsvsdct_{v}.so")
     if os.path.exists(p):
