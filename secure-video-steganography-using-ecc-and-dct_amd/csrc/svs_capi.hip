@@ -305,7 +305,10 @@ int launch_embed_exact(int qm, uint64_t total, hipStream_t st, const uint8_t *gr
 }
 
 #ifndef SVS_EXTRACT_EXACT_BPL
-#define SVS_EXTRACT_EXACT_BPL 2   // blocks per lane of the one-row pocketfft-identical extract kernel: 2 = 16-byte row loads, medians 0.768 vs 0.806 ms per 600 x 4K and 0.114 vs 0.125 per 300 x 1080p (minima equal; profiles/r04_ab_extract_bpl.txt)
+#define SVS_EXTRACT_EXACT_BPL 1   // blocks per lane of the one-row pocketfft-identical extract kernel.  Round 4 took 2 (16-byte row loads) on one
+                                  // in-process A/B (medians 0.768 vs 0.806 ms per 600 x 4K); the same A/B on four more boxes and against the round-2
+                                  // library has one block per lane ahead by 0.1 - 3 % on every large batch and level at 300 x 1080p
+                                  // (37 instead of 54 VGPRs): profiles/r05_ab_extract_bpl.txt.  Back to 1.
 #endif
 template <int QM>
 int launch_extract_exact(int rows, uint64_t total, hipStream_t st, const uint8_t *gray, const svs::Geometry &g,

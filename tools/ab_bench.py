@@ -29,7 +29,11 @@ FLAGS = {"fast": 0, "exact": 1, "guarded": 2}[a.mode]       # SVS_EXACT_POCKETFF
 def load(path):
     lib = C.CDLL(os.path.abspath(path))
     for name, (res, args) in native.SIGNATURES.items():
-        fn = getattr(lib, name); fn.restype = res; fn.argtypes = args
+        try:
+            fn = getattr(lib, name)
+        except AttributeError:      # a library of an earlier round (lib/variants/libsvsdct_r02.so) lacks the newer entry points
+            continue
+        fn.restype = res; fn.argtypes = args
     return lib
 
 libs = [(os.path.basename(p).replace("libsvsdct", "").replace(".so", "") or "base", load(p), None) for p in a.libs]
