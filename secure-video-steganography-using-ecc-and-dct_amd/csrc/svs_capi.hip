@@ -2,6 +2,7 @@
 // Build: hipcc --offload-arch=gfx950 -O3 -shared -fPIC  (see csrc/Makefile)
 #include "svsdct.h"
 #include "svs_device.hpp"
+#include "svs_stage.hpp"
 
 #include <cstdarg>
 #include <cstdio>
@@ -357,18 +358,15 @@ struct DevBuf {  // RAII (measurement hooks of the experiments library)
 //     all three download, and the batch moves at the SERIAL rate of the link, 26.6 instead of 40+ Gpixel/s,
 //     profiles/r05_pcie_rate.txt.)  The payload is uploaded once; every chunk indexes it by bit offset.
 //   * a host buffer that is page-locked (svs_host_alloc, hipHostMalloc, hipHostRegister) is the source / target of the DMA
-//     itself; pageable memory goes through the runtime's staging (uploads at the same rate, downloads at about half of it:
-//     hand the library page-locked OUTPUT buffers - svsdct/hostmem.py does).
+//     itself; pageable memory goes through the runtime's staging (uploads at the same rate, downloads at about half of it,
+//     a FRESH pageable result array - page faults - at a quarter: hand the library page-locked OUTPUT buffers, as
+//     svsdct/hostmem.py does.  Page-locking a pageable output for the duration of the call - hipHostRegister - was measured:
+//     17.5 instead of 22 ms per 32 x 4K into fresh arrays, but 0.54 instead of 0.45 ms per single 4K frame: not kept,
+//     profiles/r05_pcie_rate.txt (G)).
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int kStageStreams = 2;      // st[0] = up (H2D copies + kernels), st[1] = down (D2H copies)
 constexpr int kChunkEvents = 32;      // "kernel of chunk k done" events, reused round-robin (a stream wait captures the
                                       // event's record at the time of the call, so re-recording one later is safe)
-#ifndef SVS_STAGE_CHUNK_BYTES
-#define SVS_STAGE_CHUNK_BYTES (8u << 20)     // largest chunk of frames
-#endif
-#ifndef SVS_STAGE_CHUNK_MIN
-#define SVS_STAGE_CHUNK_MIN (4u << 20)       // smallest (a batch below twice this travels in one piece)
-#endif
 
 struct Grow {   // grow-only device buffer
     void *p = nullptr;
@@ -468,41 +466,14 @@ struct StageGuard {   // runs stage_finish on every exit path of an entry point
     ~StageGuard() { if (c) (void)stage_finish(*c); }
 };
 
-// A chunk of a batch: frames [f0, f0 + nf) x pixel rows [r0, r0 + rows); nf > 1 only with whole frames (r0 = 0, rows = H).
-struct Chunk {
-    int32_t f0, nf, r0, rows;
-};
+using svs::Chunk;
+using svs::chunk_budget;
+using svs::for_each_chunk;
 
-// Cuts a batch of n_frames frames of H rows (row_bytes bytes of payload per row) into chunks of about `target` bytes: bands of
-// block rows when a frame is larger than that, groups of whole frames otherwise.
-template <class F>
-void for_each_chunk(int32_t n_frames, int32_t H, size_t row_bytes, size_t target, F &&fn) {
-    const size_t frame_bytes = (size_t)H * row_bytes;
-    if (frame_bytes > target && H > 8) {
-        int32_t band = (int32_t)((target / row_bytes) & ~(size_t)7);
-        if (band < 8) band = 8;
-        // equal bands rather than a short last one
-        const int32_t pieces = (H + band - 1) / band;
-        band = (((H / 8) + pieces - 1) / pieces) * 8;
-        for (int32_t f = 0; f < n_frames; ++f)
-            for (int32_t r = 0; r < H; r += band) fn(Chunk{f, 1, r, r + band <= H ? band : H - r});
-    } else {
-        int32_t group = (int32_t)(target / (frame_bytes ? frame_bytes : 1));
-        if (group < 1) group = 1;
-        for (int32_t f = 0; f < n_frames; f += group) fn(Chunk{f, f + group <= n_frames ? group : n_frames - f, 0, H});
-    }
-}
-
-// chunk size of a batch of `total` bytes: an eighth of it within [4 MB, 8 MB].  A chunk costs about 33 us of host time (two
-// copies, the kernel launch, the event and its wait), so small chunks lose more than their overlap wins: one 4K frame is
-// fastest as two bands of 4 MB (0.34 ms against 0.38 in one piece and 0.49 in eight), a 1080p frame in one piece, a batch of
-// 32 4K frames in chunks of 8 MB (6.2 ms against 9.5 in one piece) - tools/stage_chunk_sweep.py, profiles/r05_pcie_rate.txt.
-// The experiments library's SVS_STAGE_CHUNK_KB overrides the rule.
+// svs_stage.hpp's rule; the experiments library's SVS_STAGE_CHUNK_KB overrides it
 size_t stage_chunk_bytes(uint64_t total) {
     const uint32_t forced = knob("SVS_STAGE_CHUNK_KB", 0);
-    if (forced) return (size_t)forced << 10;
-    const uint64_t eighth = total / 8;
-    return (size_t)(eighth < SVS_STAGE_CHUNK_MIN ? SVS_STAGE_CHUNK_MIN : (eighth > SVS_STAGE_CHUNK_BYTES ? SVS_STAGE_CHUNK_BYTES : eighth));
+    return forced ? (size_t)forced << 10 : svs::stage_chunk_rule(total);
 }
 
 template <int QM, bool EXACT>
@@ -845,14 +816,6 @@ static int stage_payload_ascii(HostStage &c, const char *bits_ascii, uint64_t us
                        static_cast<uint32_t *>(c.bits.p), words);
     SVS_HIP(hipGetLastError());
     return SVS_OK;
-}
-
-// bits a chunk that starts at global block g0 sees of a budget of `pass_bits` bits (pass_bits = 1 with nothing embeddable:
-// "non-empty payload", every block is round-tripped - for every chunk alike)
-static uint64_t chunk_budget(uint64_t pass_bits, uint64_t use, uint64_t g0, uint32_t n) {
-    if (use == 0) return pass_bits;
-    const uint64_t before = g0 * (uint64_t)n;
-    return pass_bits > before ? pass_bits - before : 0;
 }
 
 // svs_embed (payload = packed MSB-first bits, indexed by bit_offset) and svs_embed_str (payload = n_bits '0' / '1' characters,

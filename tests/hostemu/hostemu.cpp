@@ -10,6 +10,7 @@
 #include <cstring>
 
 #include "svs_block.hpp"
+#include "svs_stage.hpp"
 
 namespace {
 
@@ -277,6 +278,21 @@ uint64_t emu_qim_change_mismatches(const float *c, const uint8_t *bit, uint64_t 
     }
     return bad;
 }
+
+// the chunk plan of the host-pointer entry points (csrc/svs_stage.hpp): -> number of chunks; out[4 k ..] = f0, nf, r0, rows
+// of chunk k (at most max_chunks are written); target_bytes = 0 takes the built-in rule for a batch of total_bytes
+uint64_t emu_plan_chunks(int32_t n_frames, int32_t H, uint64_t row_bytes, uint64_t total_bytes, uint64_t target_bytes, int32_t *out,
+                         uint64_t max_chunks) {
+    uint64_t k = 0;
+    svs::for_each_chunk(n_frames, H, (size_t)row_bytes, (size_t)(target_bytes ? target_bytes : svs::stage_chunk_rule(total_bytes)),
+                        [&](const svs::Chunk &c) {
+                            if (k < max_chunks) { out[4 * k] = c.f0; out[4 * k + 1] = c.nf; out[4 * k + 2] = c.r0; out[4 * k + 3] = c.rows; }
+                            ++k;
+                        });
+    return k;
+}
+
+uint64_t emu_chunk_budget(uint64_t pass_bits, uint64_t use, uint64_t g0, uint32_t n) { return svs::chunk_budget(pass_bits, use, g0, n); }
 
 void emu_idct8(const float *X, float *x) {
     float a[8], b[8];

@@ -207,7 +207,7 @@ def hostemu():
         return _EMU
     src = os.path.join(REPO, "tests", "hostemu", "hostemu.cpp")
     out = os.path.join(REPO, "tests", "hostemu", "libsvs_hostemu.so")
-    deps = [src, os.path.join(CSRC, "svs_block.hpp")]
+    deps = [src, os.path.join(CSRC, "svs_block.hpp"), os.path.join(CSRC, "svs_stage.hpp")]
     stale = not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps)
     if stale and os.path.exists(out) and os.path.exists("/dev/kfd"):
         stale = False      # on a GPU box use the library built by build(): no compiler child processes there
@@ -231,8 +231,23 @@ def hostemu():
     lib.emu_qim_change_mismatches.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_double]
     lib.emu_quant_mismatches.restype = ctypes.c_uint64
     lib.emu_quant_mismatches.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_double]
+    lib.emu_plan_chunks.restype = ctypes.c_uint64
+    lib.emu_plan_chunks.argtypes = [ctypes.c_int32, ctypes.c_int32, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_void_p,
+                                    ctypes.c_uint64]
+    lib.emu_chunk_budget.restype = ctypes.c_uint64
+    lib.emu_chunk_budget.argtypes = [ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint32]
     _EMU = lib
     return lib
+
+
+def plan_chunks(n_frames, height, row_bytes, total_bytes=None, target_bytes=0):
+    """the chunk plan of the host-pointer entry points (csrc/svs_stage.hpp) -> list of (f0, nf, r0, rows)"""
+    lib = hostemu()
+    total = n_frames * height * row_bytes if total_bytes is None else total_bytes
+    n = lib.emu_plan_chunks(n_frames, height, row_bytes, total, target_bytes, None, 0)
+    out = np.zeros((max(n, 1), 4), np.int32)
+    assert lib.emu_plan_chunks(n_frames, height, row_bytes, total, target_bytes, out.ctypes.data, n) == n
+    return [tuple(int(v) for v in row) for row in out[:n]]
 
 
 def emu_embed(frames, delta, n_ac, bits, bit_offset=0, exact=False, replayed=None):
