@@ -22,20 +22,24 @@ from . import native
 
 _GRANULE = 1 << 16               # buffer sizes are rounded up to 64 KB
 _KEEP_BYTES = 512 << 20          # free buffers kept for reuse; beyond that they are returned to the driver
+_MAX_LIVE_BYTES = 4 << 30        # page-locked bytes in the hands of callers + in the pool; beyond that (a caller that keeps every
+                                 # stego frame of a clip) arrays are ordinary pageable ones: slower downloads, same results
 _lock = threading.Lock()
 _free: dict[int, list[int]] = {}  # size -> pointers
 _free_bytes = 0
-stats = {"allocated": 0, "reused": 0, "released": 0}
+_live_bytes = 0                   # allocated from the driver and not yet returned to it
+stats = {"allocated": 0, "reused": 0, "released": 0, "pageable": 0}
 
 
 def _give_back(ptr: int, size: int) -> None:
-    global _free_bytes
+    global _free_bytes, _live_bytes
     try:
         with _lock:
             if _free_bytes + size <= _KEEP_BYTES:
                 _free.setdefault(size, []).append(ptr)
                 _free_bytes += size
                 return
+            _live_bytes -= size
         native.load().svs_host_free(C.c_void_p(ptr))
         stats["released"] += 1
     except Exception:       # interpreter shutdown: the process is going away with its memory
@@ -43,9 +47,10 @@ def _give_back(ptr: int, size: int) -> None:
 
 
 def pinned_empty(shape, dtype=np.uint8) -> np.ndarray:
-    """Uninitialised array of `shape` / `dtype` in page-locked memory (needs the HIP library and a device, like every
-    product path: raises SvsNativeError otherwise)."""
-    global _free_bytes
+    """Uninitialised array of `shape` / `dtype` in page-locked memory (needs the HIP library, like every product path: raises
+    SvsNativeError when it cannot be loaded).  When the driver refuses more page-locked memory, or _MAX_LIVE_BYTES of it are out
+    already, the array is an ordinary pageable one - the library handles both."""
+    global _free_bytes, _live_bytes
     dtype = np.dtype(dtype)
     shape = tuple(int(s) for s in (shape if isinstance(shape, (tuple, list)) else (shape,)))
     nbytes = int(np.prod(shape, dtype=np.int64)) * dtype.itemsize
@@ -58,8 +63,18 @@ def pinned_empty(shape, dtype=np.uint8) -> np.ndarray:
             _free_bytes -= size
             stats["reused"] += 1
     if ptr is None:
+        lib = native.load()
+        with _lock:
+            room = _live_bytes + size <= _MAX_LIVE_BYTES
+            if room:
+                _live_bytes += size
         p = C.c_void_p()
-        native.check(native.load().svs_host_alloc(C.byref(p), size), "svs_host_alloc")
+        if not room or lib.svs_host_alloc(C.byref(p), size) != native.SVS_OK or not p.value:
+            if room:
+                with _lock:
+                    _live_bytes -= size
+            stats["pageable"] += 1
+            return np.empty(shape, dtype)
         ptr = p.value
         stats["allocated"] += 1
     raw = (C.c_uint8 * size).from_address(ptr)
@@ -76,11 +91,12 @@ def pinned_copy(a: np.ndarray) -> np.ndarray:
 
 def trim() -> None:
     """Return every free buffer to the driver (tests; long-lived processes after a large batch)."""
-    global _free_bytes
+    global _free_bytes, _live_bytes
     with _lock:
         pending = [(p, s) for s, ps in _free.items() for p in ps]
         _free.clear()
         _free_bytes = 0
+        _live_bytes -= sum(s for _, s in pending)
     for p, _ in pending:
         native.load().svs_host_free(C.c_void_p(p))
         stats["released"] += 1

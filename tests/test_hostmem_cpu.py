@@ -17,8 +17,11 @@ class _FakeLib:
     def __init__(self):
         self.live = {}
         self.allocs = self.frees = 0
+        self.refuse = False
 
     def svs_host_alloc(self, ref, size):
+        if self.refuse:
+            return native.SVS_ERR_HIP
         buf = C.create_string_buffer(size)
         ref._obj.value = C.addressof(buf)
         self.live[ref._obj.value] = buf
@@ -38,6 +41,7 @@ def fake(monkeypatch):
     hostmem.trim()
     for k in hostmem.stats:
         hostmem.stats[k] = 0
+    assert hostmem._live_bytes == 0
     yield lib
     gc.collect()
     hostmem.trim()
@@ -112,3 +116,24 @@ def test_ascii_address_is_the_strings_own_buffer():
     for bad in ("01€1", "0é1"):
         with pytest.raises(ValueError):
             batch._ascii_address(bad)
+
+
+def test_beyond_the_cap_or_when_the_driver_refuses_arrays_are_pageable(fake, monkeypatch):
+    """a caller that keeps every result (a list of all stego frames of a clip) must not exhaust page-locked memory: beyond
+    _MAX_LIVE_BYTES, and whenever svs_host_alloc fails, pinned_empty hands out ordinary arrays - slower downloads, same results"""
+    monkeypatch.setattr(hostmem, "_MAX_LIVE_BYTES", 3 * 65536)
+    kept = [hostmem.pinned_empty(60000) for _ in range(5)]
+    assert fake.allocs == 3 and hostmem.stats["pageable"] == 2
+    assert all(a.shape == (60000,) and a.dtype == np.uint8 for a in kept)
+    del kept
+    gc.collect()
+    again = hostmem.pinned_empty(60000)
+    assert hostmem.stats["reused"] == 1 and fake.allocs == 3
+    del again
+    fake.refuse = True
+    big = hostmem.pinned_empty((4, 70000))               # a size class with nothing in the pool: the driver says no
+    assert big.shape == (4, 70000) and hostmem.stats["pageable"] == 3
+    fake.refuse = False
+    gc.collect()
+    hostmem.trim()
+    assert hostmem._live_bytes == 0

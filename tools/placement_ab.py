@@ -21,6 +21,7 @@ from testlib import EXPERIMENT_HOOKS
 ap = argparse.ArgumentParser()
 ap.add_argument("--pairs", type=int, default=6); ap.add_argument("--burst", type=int, default=8); ap.add_argument("--rounds", type=int, default=3)
 ap.add_argument("--n-ac", type=int, default=3)
+ap.add_argument("--chunks", default="", help="comma list of further SVS_EMBED_XCD_CHUNK values (runs of that many tiles per XCD)")
 a = ap.parse_args()
 
 
@@ -34,7 +35,9 @@ def load(name, hooks=False):
 base = load("libsvsdct.so")
 exp = load("variants/libsvsdct_exp.so", hooks=True)
 configs = [("base", base, {}), ("map0", exp, {"SVS_EMBED_XCD_CHUNK": "0"}), ("map32", exp, {"SVS_EMBED_XCD_CHUNK": "32"})]
-for v in ("nosc1", "plain"):
+for ch in [c for c in a.chunks.split(",") if c]:
+    configs.append((f"map{ch}", exp, {"SVS_EMBED_XCD_CHUNK": ch}))
+for v in (() if a.chunks else ("nosc1", "plain")):
     p = os.path.join(PKG, "lib", "variants", f"libsvsdct_{v}.so")
     if os.path.exists(p):
         configs.append((v, load(f"variants/libsvsdct_{v}.so"), {}))
