@@ -1202,3 +1202,22 @@ def test_string_payload_entry_points_equal_the_packed_ones():
         assert text == batch.unpack_to_str(packed, n_bits)
     with pytest.raises(ValueError):
         batch.embed_frames_str(cover, 8, 3, "01\u20ac")                    # not a one-byte-per-character string
+
+
+def test_fused_colour_host_calls_in_bands_and_frame_groups():
+    """svs_embed_bgr moves BGR frames through the same staging pipeline as svs_embed (csrc/svs_capi.hip): 1080p frames (6.2 MB of
+    BGR each) travel in two bands, 640 x 480 frames in groups; the budget ends inside a later chunk; gray reference included.
+    Same result as the gray path on the converted frames."""
+    rng = np.random.default_rng(23)
+    for (f, h, w, n_ac, delta) in ((3, 1080, 1920, 10, 20), (12, 480, 640, 3, 8)):
+        bgr = rng.integers(0, 256, (f, h, w, 3), dtype=np.uint8)
+        gray = np.stack([d_gray_default(x) for x in bgr])
+        cap = batch.capacity_bits(f, h, w, n_ac)
+        payload = synth.synthetic_bits(cap - cap // (2 * f) - 3, seed=f)
+        want, want_used = batch.embed_frames(gray, delta, n_ac, payload)
+        got_bgr, got_gray, used = batch.embed_bgr_frames(bgr, delta, n_ac, payload)
+        assert used == want_used == payload.size
+        assert np.array_equal(got_gray, gray)
+        assert np.array_equal(got_bgr, np.repeat(want[..., None], 3, axis=3))
+        packed, n_bits = batch.extract_bgr_frames(got_bgr, delta, n_ac)
+        assert n_bits == cap and np.array_equal(np.unpackbits(packed, count=payload.size), payload)
