@@ -30,8 +30,11 @@ def experiments_library():
     global _exp_lib
     if _exp_lib is None:
         from svsdct import native
-        if not os.path.exists(EXP_LIB_PATH):
-            raise RuntimeError(f"{EXP_LIB_PATH} is missing: run `python __graft_entry__.py` (make -C csrc exp)")
+        if not os.path.exists(EXP_LIB_PATH):       # normally built by __graft_entry__.build(); hipcc is in the image (about 25 s)
+            try:
+                subprocess.run(["make", "-C", CSRC, "exp"], check=True, capture_output=True, timeout=600)
+            except (OSError, subprocess.SubprocessError) as exc:
+                raise RuntimeError(f"{EXP_LIB_PATH} is missing and could not be built ({exc}): run `python __graft_entry__.py`") from exc
         lib = ctypes.CDLL(EXP_LIB_PATH)
         for name, (res, args) in {**native.SIGNATURES, **EXPERIMENT_HOOKS}.items():
             fn = getattr(lib, name)
