@@ -343,7 +343,7 @@ struct DevBuf {  // RAII (measurement hooks of the experiments library)
 };
 
 // ---------------------------------------------------------------------------------------------------------------------
-// Staging context of the HOST-pointer entry points (svs_embed / svs_extract / svs_embed_bgr / svs_extract_bgr).
+// Staging context of the HOST-pointer entry points (svs_embed / svs_extract, their _str and _bgr forms).
 // What the reference's per-frame call sites hit (embed_process.py:117-121, extract_process.py:64-68: NumPy arrays in, NumPy
 // arrays out), so it has to run at the rate of the PCIe link, not of hipMalloc:
 //   * one context per HOST THREAD (thread_local): two non-blocking streams and grow-only device buffers.  Nothing is
@@ -403,9 +403,14 @@ int stage_acquire(HostStage **out) {
     HostStage &c = t_stage;
     if (c.device != dev) {
         c.release();
-        for (auto &s : c.st) SVS_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
-        for (auto &e : c.chunk_done) SVS_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        c.device = dev;
+        c.device = dev;                    // from here on release() undoes whatever has been created
+        hipError_t err = hipSuccess;
+        for (auto &s : c.st) if (err == hipSuccess) err = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+        for (auto &e : c.chunk_done) if (err == hipSuccess) err = hipEventCreateWithFlags(&e, hipEventDisableTiming);
+        if (err != hipSuccess) {
+            c.release();
+            return fail(SVS_ERR_HIP, "creating the staging context failed: %s", hipGetErrorString(err));
+        }
     }
     *out = &c;
     return SVS_OK;
