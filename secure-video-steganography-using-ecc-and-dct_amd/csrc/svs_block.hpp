@@ -979,15 +979,253 @@ SVS_HD void guard_apply(uint32_t (&rx)[8], uint32_t (&ry)[8], const float (&fl)[
 #undef SVS_OUTCOL
 }
 
-// decide, then apply: on return rx/ry hold the block's stego pixels - or, when the result is true (undecided), its original
-// pixels, untouched (the host emulation and the in-place / fused-colour kernels)
+// decide, then apply, in the float domain: on return rx/ry hold the block's stego pixels - or, when the result is true
+// (undecided), its original pixels, untouched.  The saturating form: what embed_block_guarded falls back to for a block in
+// which a pixel could clip at 0 / 255.
 template <int QM>
-SVS_HD bool embed_block_guarded(uint32_t (&rx)[8], uint32_t (&ry)[8], uint32_t n, uint32_t nb, uint32_t hi, uint32_t lo,
-                                const QimParams &qp) {
+SVS_HD bool embed_block_guarded_float(uint32_t (&rx)[8], uint32_t (&ry)[8], uint32_t n, uint32_t nb, uint32_t hi, uint32_t lo,
+                                      const QimParams &qp) {
     float fl[8];
     const bool undecided = guard_decide<QM>(rx, ry, n, nb, hi, lo, qp, fl);
     if (!undecided) guard_apply(rx, ry, fl);
     return undecided;
+}
+
+// One coefficient through the quantiser, in the float domain: change = fl(q' delta) - c with q' = round-half-even(c / delta)
+// forced to the parity of `bit` (config_and_setup.py:148-156).  t + 1.5 * 2^23 rounds t to the nearest-even integer q AND leaves
+// q in the low mantissa bits of the sum (|t| < 2^22: delta >= 1/4 and |c| <= 2040 here), so the parity is forced on the bit
+// pattern and q' comes back by subtracting the constant - no conversion to an integer and back (those are 1.6-slot
+// instructions, profiles/r04_valu_issue_rate.txt).  Same results as quant_index / force_parity (tests: guarded mode vs the oracle).
+template <int QM>
+SVS_HD float qim_change(float c, uint32_t bit, const QimParams &qp) {
+    if constexpr (QM == QM_DOUBLE) {
+        const int q = force_parity(quant_index<QM>(c, qp), (int)bit);
+        return (float)((double)q * qp.delta_d) - c;
+    } else {
+        const float kMagic = 12582912.0f;   // 1.5 * 2^23
+        const float t = c * qp.inv_delta_f;
+        float m = t + kMagic;
+#if defined(SVS_QUANT_ALWAYS_DIVIDE)
+        m = rintf(c / qp.delta_f) + kMagic;
+#else
+        if constexpr (QM != QM_POW2) {
+            const float r = m - kMagic;
+            const float miss = fabsf(fabsf(t - r) - 0.5f);       // distance of t from the nearest half-integer
+            if (miss <= fabsf(t) * 4.76837158203125e-7f)          // see quant_index
+                m = rintf(c / qp.delta_f) + kMagic;
+        }
+#endif
+        const uint32_t mb = (__builtin_bit_cast(uint32_t, m) & ~1u) | bit;
+        const float qf = __builtin_bit_cast(float, mb) - kMagic;
+        return qf * qp.delta_f - c;
+    }
+}
+
+// ---- one coefficient row in the INTEGER domain (round 6) --------------------------------------------------------------
+// With n <= 7 the change is the same in all 8 rows of a pixel column, so the block's result is pixel + d[x] with eight
+// integers d[x] = floor(change of column x).  When no pixel of the block can leave [0, 255] - min pixel + min d >= 0 and
+// max pixel + max d <= 255 - the saturation of the store never acts, and because  sum_j (p_j + d_j) 256^j = P + D  with
+// D = sum_j d_j 256^j (mod 2^32) and every p_j + d_j a byte, the four stego bytes of a row dword are ONE 32-bit add of the
+// packed column deltas: 16 v_add_u32 per block instead of 64 x (byte -> float, add, float -> saturated byte).  The price is
+// the block's min / max pixel - packed 16-bit min / max on the even / odd byte lanes the column sums split the rows into
+// anyway.  The decision (BETA, `worst`) is guard_decide's, value for value; the quantiser step is qim_change (the float-
+// domain form of the two-row kernel, same results as quant_index / force_parity for |c / delta| < 2^22: delta >= 1/4 here).
+SVS_HD uint32_t pk_min_u16(uint32_t a, uint32_t b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef uint16_t u16x2 __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b)));
+#else
+    const uint32_t al = a & 0xffffu, bl = b & 0xffffu, ah = a >> 16, bh = b >> 16;
+    return (al < bl ? al : bl) | ((ah < bh ? ah : bh) << 16);
+#endif
+}
+SVS_HD uint32_t pk_max_u16(uint32_t a, uint32_t b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef uint16_t u16x2 __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b)));
+#else
+    const uint32_t al = a & 0xffffu, bl = b & 0xffffu, ah = a >> 16, bh = b >> 16;
+    return (al > bl ? al : bl) | ((ah > bh ? ah : bh) << 16);
+#endif
+}
+SVS_HD int floor_to_int(float x) {   // (int)floor(x): v_cvt_flr_i32_f32
+#if defined(__HIP_DEVICE_COMPILE__)
+    int r;
+    asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(r) : "v"(x));
+    return r;
+#else
+    return (int)floorf(x);
+#endif
+}
+SVS_HD int imin3(int a, int b, int c) { const int m = a < b ? a : b; return m < c ? m : c; }
+SVS_HD int imax3(int a, int b, int c) { const int m = a > b ? a : b; return m > c ? m : c; }
+
+// pins three running values at this point of the instruction stream (device only): an opaque, ordered use-and-redefinition,
+// so that the chains feeding them are complete here and the operands they consumed are dead - without it the instruction
+// selector lets the min / max / sum-of-squares chains of guard_decide_int trail the transform, with their 32 lane splits alive
+#if defined(__HIP_DEVICE_COMPILE__)
+#define SVS_PIN3(a, b, c) asm volatile("" : "+v"(a), "+v"(b), "+v"(c))
+#else
+#define SVS_PIN3(a, b, c) ((void)0)
+#endif
+#ifndef SVS_ROW1_FENCE_EVERY
+#define SVS_ROW1_FENCE_EVERY 2
+#endif
+#ifndef SVS_ROW1_FENCE
+#define SVS_ROW1_FENCE() SVS_SCHED_FENCE()
+#endif
+#define SVS_ROW1_UNDECIDED 1u   // guard_decide_int: BETA does not separate some column's change from the integer grid
+#define SVS_ROW1_MAY_CLIP 2u    //                   min pixel + min d < 0 or max pixel + max d > 255: the plain add must not be used
+
+// the eight column deltas of a block as two's complement 16-bit lanes: columns (0, 2), (1, 3), (4, 6), (5, 7) - the form the
+// saturating store adds to the even / odd byte lanes of a row dword.  (|d| < 2^14 for every delta the guarded range admits:
+// 1.5 * 4096 * sum of 7 basis values * a(0) < 5700.)
+struct ColumnDeltas {
+    uint32_t e_lo, o_lo, e_hi, o_hi;
+};
+// ... and as ONE 32-bit addend per row dword: sum_j d_j 256^j (mod 2^32) of columns 0..3 (e = e_lo, o = o_lo) / 4..7.  A lane
+// pair (a, b) read as an integer is a + 65536 b + 65536 [a < 0]; without the last term it is the addend of its two columns.
+SVS_HD uint32_t packed_addend(uint32_t e, uint32_t o) {
+    const uint32_t ev = e - ((e & 0x8000u) << 1), ov = o - ((o & 0x8000u) << 1);
+    return ev + (ov << 8);
+}
+
+SVS_HD uint32_t pk_add_i16(uint32_t a, uint32_t b) {   // lane-wise 16-bit add (wraps; the callers stay far inside the range)
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef int16_t i16x2 __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(uint32_t, __builtin_bit_cast(i16x2, a) + __builtin_bit_cast(i16x2, b));
+#else
+    return ((a + b) & 0xffffu) | (((a >> 16) + (b >> 16)) << 16);
+#endif
+}
+SVS_HD uint32_t pk_clamp_u8_i16(uint32_t a) {   // lane-wise clamp of signed 16-bit lanes to [0, 255]
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef int16_t i16x2 __attribute__((ext_vector_type(2)));
+    const i16x2 zero = {0, 0}, top = {255, 255};
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_elementwise_max(__builtin_bit_cast(i16x2, a), zero), top));
+#else
+    uint32_t r = 0;
+    for (int h = 0; h < 2; ++h) {
+        int v = (int16_t)(a >> (16 * h));
+        v = v < 0 ? 0 : (v > 255 ? 255 : v);
+        r |= (uint32_t)v << (16 * h);
+    }
+    return r;
+#endif
+}
+
+// NFIX (1..7, or 0 = run-time n): the coefficient count at compile time - transform outputs nobody reads and inverse inputs
+// that are known zeros disappear from the code (values unchanged: x + 0 and fma(0, c, x) are exact).
+// -> SVS_ROW1_* flags and the column deltas (meaningful unless SVS_ROW1_UNDECIDED).
+template <int QM, int NFIX = 0>
+SVS_HD uint32_t guard_decide_int(const uint32_t (&rx)[8], const uint32_t (&ry)[8], uint32_t n_rt, uint32_t nb, uint32_t hi,
+                                 const QimParams &qp, ColumnDeltas &cd) {
+    static_assert(NFIX >= 0 && NFIX <= 7, "one coefficient row");
+    const uint32_t n = NFIX ? (uint32_t)NFIX : n_rt;
+    float V[8];
+    uint32_t S = 0, Q = 0, mn = 0x00ff00ffu, mx = 0u;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        uint32_t te = 0, to = 0;   // columns (0, 2) and (1, 3) of this half as 16-bit lanes, each <= 2040
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const uint32_t w = half ? ry[r] : rx[r];
+            const uint32_t e = w & 0x00ff00ffu, o = (w >> 8) & 0x00ff00ffu;
+            te += e;
+            to += o;
+            Q = dot4_u8(w, w, Q);
+            mn = pk_min_u16(pk_min_u16(mn, e), o);
+            mx = pk_max_u16(pk_max_u16(mx, e), o);
+            if ((r & (SVS_ROW1_FENCE_EVERY - 1)) == SVS_ROW1_FENCE_EVERY - 1) SVS_PIN3(mn, mx, Q);
+        }
+        V[4 * half + 0] = (float)(te & 0xffffu) * SVS_A0;
+        V[4 * half + 1] = (float)(to & 0xffffu) * SVS_A0;
+        V[4 * half + 2] = (float)(te >> 16) * SVS_A0;
+        V[4 * half + 3] = (float)(to >> 16) * SVS_A0;
+        const uint32_t t = te + to;
+        S += (t & 0xffffu) + (t >> 16);
+        SVS_ROW1_FENCE();
+    }
+    float D[8];
+    pf::dct2_8(V, D);   // row 0 of the coefficient matrix, bit-identical to scipy's
+    SVS_ROW1_FENCE();
+#pragma unroll
+    for (int k = 1; k < 8; ++k) {
+        float change = 0.0f;
+        if ((NFIX == 0 || k <= NFIX) && (uint32_t)k <= n)  // wave-uniform; the budget is applied below, for the one block it concerns
+            change = qim_change<QM>(D[k], (hi >> (32 - k)) & 1u, qp);
+        D[k] = change;
+    }
+    if (nb < n) {   // the block the payload ends in: coefficients past the budget stay as they are (config_and_setup.py:141)
+#pragma unroll
+        for (int k = 1; k < 8; ++k)
+            if ((uint32_t)(k - 1) >= nb) D[k] = 0.0f;
+    }
+    D[0] = 0.0f;
+    float P[8];
+    idct8<NFIX ? NFIX + 1 : 8, true>(D, P);
+    // BETA for this block: 64 Q - S^2 = 64 * (sum of squared deviations from the mean), an exact integer < 2^32
+    const float spread = guard_sqrt((float)(64u * Q - S * S));
+    const float beta = fmaf(qp.g_sum, (float)S, fmaf(qp.g_resid, spread, qp.g_delta));
+    float worst = 0.0f;   // largest |frac(change) - 1/2| among the 8 columns
+    int d[8];
+#pragma unroll
+    for (int x = 0; x < 8; ++x) {
+        const float ch = P[x] * SVS_A0;
+        // v_fract_f32 is ch - floor(ch) (exact for these magnitudes) except that it stays below 1 where that difference would
+        // round up to 1.0 (ch a hair below an integer): 1 - 2^-24 is flagged like 1.0 (BETA >= 2^-20)
+        worst = fmaxf(worst, fabsf(fract_f32(ch) - 0.5f));
+        d[x] = floor_to_int(ch);
+    }
+    uint32_t flags = (nb > 0 && !(worst < 0.5f - beta)) ? SVS_ROW1_UNDECIDED : 0u;   // nb == 0: the reference never enters the block (:130,:132)
+    const int dmin = imin3(imin3(d[0], d[1], d[2]), imin3(d[3], d[4], d[5]), d[6] < d[7] ? d[6] : d[7]);
+    const int dmax = imax3(imax3(d[0], d[1], d[2]), imax3(d[3], d[4], d[5]), d[6] > d[7] ? d[6] : d[7]);
+    const uint32_t mnl = mn & 0xffffu, mnh = mn >> 16, mxl = mx & 0xffffu, mxh = mx >> 16;
+    const int pmin = (int)(mnl < mnh ? mnl : mnh), pmax = (int)(mxl > mxh ? mxl : mxh);
+    if (pmin + dmin < 0 || pmax + dmax > 255) flags |= SVS_ROW1_MAY_CLIP;
+    cd.e_lo = ((uint32_t)d[0] & 0xffffu) | ((uint32_t)d[2] << 16);
+    cd.o_lo = ((uint32_t)d[1] & 0xffffu) | ((uint32_t)d[3] << 16);
+    cd.e_hi = ((uint32_t)d[4] & 0xffffu) | ((uint32_t)d[6] << 16);
+    cd.o_hi = ((uint32_t)d[5] & 0xffffu) | ((uint32_t)d[7] << 16);
+    return flags;
+}
+
+// the stores: pixel + d[column], clipped to [0, 255] (trunc(clip(x + c)) == clip(x + floor(c)) for integer x, :171)
+SVS_HD void apply_deltas_plain(uint32_t (&rx)[8], uint32_t (&ry)[8], const ColumnDeltas &cd) {   // nothing can clip
+    const uint32_t lo = packed_addend(cd.e_lo, cd.o_lo), hi = packed_addend(cd.e_hi, cd.o_hi);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) { rx[r] += lo; ry[r] += hi; }
+}
+SVS_HD uint32_t add_clip_dword(uint32_t w, uint32_t de, uint32_t dodd) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    // opaque copy: without it the compiler keeps the 64 lane splits of guard_decide_int alive for this (rare) path - 50 VGPRs
+    asm("" : "+v"(w));
+#endif
+    const uint32_t e = pk_clamp_u8_i16(pk_add_i16(w & 0x00ff00ffu, de));
+    const uint32_t o = pk_clamp_u8_i16(pk_add_i16((w >> 8) & 0x00ff00ffu, dodd));
+    return e | (o << 8);
+}
+SVS_HD void apply_deltas_clipped(uint32_t (&rx)[8], uint32_t (&ry)[8], const ColumnDeltas &cd) {
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        rx[r] = add_clip_dword(rx[r], cd.e_lo, cd.o_lo);
+        ry[r] = add_clip_dword(ry[r], cd.e_hi, cd.o_hi);
+    }
+}
+
+// decide, then apply: on return rx/ry hold the block's stego pixels - or, when the result is true (undecided), its original
+// pixels, untouched (the host emulation, the one-block-per-lane and fused-colour kernels; embed_row1_kernel chooses the
+// store form per WAVE instead of per lane)
+template <int QM, int NFIX = 0>
+SVS_HD bool embed_block_guarded(uint32_t (&rx)[8], uint32_t (&ry)[8], uint32_t n, uint32_t nb, uint32_t hi, uint32_t lo,
+                                const QimParams &qp) {
+    (void)lo;   // one coefficient row: the window is its first word
+    ColumnDeltas cd;
+    const uint32_t flags = guard_decide_int<QM, NFIX>(rx, ry, n, nb, hi, qp, cd);
+    if (flags & SVS_ROW1_UNDECIDED) return true;
+    if (flags & SVS_ROW1_MAY_CLIP) apply_deltas_clipped(rx, ry, cd);
+    else apply_deltas_plain(rx, ry, cd);
+    return false;
 }
 
 // Two coefficient rows (n = 8..15), rigorous: the same construction with 64 predictions instead of 8 (the change now varies
@@ -1049,36 +1287,6 @@ SVS_HD void vertical_pf01_packed(const uint32_t (&w)[8], float (&v0)[4], float (
         for (int c = 0; c < 2; ++c)  // 16-bit lane c of half h is column 2c + h
             pf::column_outputs01((float)(c ? (t >> 16) : (t & 0xffffu)), (float)tr2[c], (float)ti2[c], (float)a1h[c], (float)b1h[c],
                                  v0[2 * c + h], v1[2 * c + h]);
-    }
-}
-
-// One coefficient through the quantiser, in the float domain: change = fl(q' delta) - c with q' = round-half-even(c / delta)
-// forced to the parity of `bit` (config_and_setup.py:148-156).  t + 1.5 * 2^23 rounds t to the nearest-even integer q AND leaves
-// q in the low mantissa bits of the sum (|t| < 2^22: delta >= 1/4 and |c| <= 2040 here), so the parity is forced on the bit
-// pattern and q' comes back by subtracting the constant - no conversion to an integer and back (those are 1.6-slot
-// instructions, profiles/r04_valu_issue_rate.txt).  Same results as quant_index / force_parity (tests: guarded mode vs the oracle).
-template <int QM>
-SVS_HD float qim_change(float c, uint32_t bit, const QimParams &qp) {
-    if constexpr (QM == QM_DOUBLE) {
-        const int q = force_parity(quant_index<QM>(c, qp), (int)bit);
-        return (float)((double)q * qp.delta_d) - c;
-    } else {
-        const float kMagic = 12582912.0f;   // 1.5 * 2^23
-        const float t = c * qp.inv_delta_f;
-        float m = t + kMagic;
-#if defined(SVS_QUANT_ALWAYS_DIVIDE)
-        m = rintf(c / qp.delta_f) + kMagic;
-#else
-        if constexpr (QM != QM_POW2) {
-            const float r = m - kMagic;
-            const float miss = fabsf(fabsf(t - r) - 0.5f);       // distance of t from the nearest half-integer
-            if (miss <= fabsf(t) * 4.76837158203125e-7f)          // see quant_index
-                m = rintf(c / qp.delta_f) + kMagic;
-        }
-#endif
-        const uint32_t mb = (__builtin_bit_cast(uint32_t, m) & ~1u) | bit;
-        const float qf = __builtin_bit_cast(float, mb) - kMagic;
-        return qf * qp.delta_f - c;
     }
 }
 

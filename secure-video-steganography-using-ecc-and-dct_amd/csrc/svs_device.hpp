@@ -586,7 +586,7 @@ struct GuardPayload {
 // still hold the ORIGINAL pixels, first_a / first_b are their first stream bits) through the worklist `entries` (CAP entries)
 // and the transposition tile `tile` (8 * SVS_GUARD_TILE floats), both private to the wave.  On return the rows of undecided
 // blocks hold the exact stego pixels.  Returns the number of blocks redone.
-template <int QM, bool TWO, int CAP = SVS_GUARD_CAP, bool KEPT = false>
+template <int QM, bool TWO, int CAP = SVS_GUARD_CAP, bool KEPT = false, int UROWS = 2>
 __device__ __forceinline__ uint32_t guard_phase2(GuardEntry *entries, float *tile, uint32_t lane, uint32_t n,
                                                  const QimParams &qp, const GuardPayload &pl,
                                                  bool und_a, uint64_t first_a, uint32_t (&ax)[8], uint32_t (&ay)[8],
@@ -625,7 +625,7 @@ __device__ __forceinline__ uint32_t guard_phase2(GuardEntry *entries, float *til
             const uint32_t idx = first + (lane >> 3);
             if (idx < todo) {
                 GuardEntry *e = &entries[idx];
-                guard_replay8<QM, 2>(e->px, e->hi, e->lo, e->nb, tile + (lane >> 3) * SVS_GUARD_TILE, lane & 7u, n, qp);
+                guard_replay8<QM, UROWS>(e->px, e->hi, e->lo, e->nb, tile + (lane >> 3) * SVS_GUARD_TILE, lane & 7u, n, qp);
             }
         }
         wave_lds_fence();
@@ -868,6 +868,179 @@ __global__ __launch_bounds__(SVS_WG, kEmbedMinWaves<U>) void embed_kernel(const 
         }
         store_rows<BPL>(stego + off, g.row_pitch, v);
     }
+}
+
+// ---------------------------------------------------------------------------------------
+// EMBED, one coefficient row (n <= 7), round 6: the streaming kernel above with the rows kept in ONE representation from
+// the load to the store and the cheap result applied in the integer domain (svs_block.hpp, guard_decide_int).
+//   * every lane loads (lanes past the end of the batch shadow its last block(s) and never store), so the row registers
+//     are defined on one path only: no copies at the joins (round 5: 173 static v_mov_b32, 61 of them on every wave's path);
+//   * a decided block costs 16 v_add_u32 instead of 192 conversion / add / saturating-conversion instructions; a WAVE in
+//     which some block could clip at 0 / 255 (a wave-uniform ballot) takes the saturating float form for all its lanes -
+//     same bytes, the old cost;
+//   * the worklist deposit / collection moves rows as the 8-byte pairs they are held in.
+// Phases 2 and 3 as in embed_kernel.  gray and stego may alias.
+// ---------------------------------------------------------------------------------------
+#ifndef SVS_ROW1_CLIP_PATH
+#define SVS_ROW1_CLIP_PATH 1
+#endif
+#ifndef SVS_ROW1_MIN_WAVES
+#define SVS_ROW1_MIN_WAVES 1
+#endif
+// Rows stay in the load / store vectors: block A = components x, y of v[r], block B (two blocks per lane) = z, w.
+template <int BPL>
+__device__ __forceinline__ void row1_block(const typename RowVec<BPL>::type (&v)[8], int which, uint32_t (&rx)[8], uint32_t (&ry)[8]) {
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        if constexpr (BPL == 2) { rx[r] = which ? v[r].z : v[r].x; ry[r] = which ? v[r].w : v[r].y; }
+        else { rx[r] = v[r].x; ry[r] = v[r].y; }
+    }
+}
+// worklist deposit / collection of one block's rows as the 8-byte halves of the row vectors they live in (volatile: the
+// load / store vectoriser would otherwise pair rows into 16-byte LDS accesses and gather their operands with v_mov)
+typedef __attribute__((address_space(3))) volatile u32x2 lds_v64;
+template <int BPL>
+__device__ __forceinline__ void row1_deposit(GuardEntry *e, const typename RowVec<BPL>::type (&v)[8], int which) {
+    lds_v64 *px = (lds_v64 *)(e->px);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        u32x2 t;
+        if constexpr (BPL == 2) { if (which) { t.x = v[r].z; t.y = v[r].w; } else { t.x = v[r].x; t.y = v[r].y; } }
+        else { t.x = v[r].x; t.y = v[r].y; }
+        px[r] = t;
+    }
+}
+template <int BPL>
+__device__ __forceinline__ void row1_collect(const GuardEntry *e, typename RowVec<BPL>::type (&v)[8], int which) {
+    const lds_v64 *px = (const lds_v64 *)(e->px);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const u32x2 t = px[r];
+        if constexpr (BPL == 2) { if (which) { v[r].z = t.x; v[r].w = t.y; } else { v[r].x = t.x; v[r].y = t.y; } }
+        else { v[r].x = t.x; v[r].y = t.y; }
+    }
+}
+
+// phase 2 of the one-row kernel: guard_phase2 on the row vectors (the payload windows are kept from phase 1)
+template <int QM, int BPL, int CAP>
+__device__ __forceinline__ uint32_t row1_phase2(GuardEntry *entries, float *tile, uint32_t lane, uint32_t n, const QimParams &qp,
+                                                uint64_t n_bits, bool und_a, bool und_b, uint64_t first_a, uint32_t hi_a, uint32_t hi_b,
+                                                typename RowVec<BPL>::type (&v)[8]) {
+    const uint64_t mask_a = __ballot(und_a);
+    const uint64_t mask_b = BPL == 2 ? __ballot(und_b) : 0ull;
+    if ((mask_a | mask_b) == 0) return 0;   // wave-uniform: the common case costs two ballots
+    const uint32_t n_a = (uint32_t)__popcll(mask_a), total = n_a + (uint32_t)__popcll(mask_b);
+    const uint32_t rank_a = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask_a >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask_a, 0u));
+    const uint32_t rank_b = n_a + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask_b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask_b, 0u));
+    for (uint32_t base = 0; base < total; base += (uint32_t)CAP) {   // wave-uniform
+        const bool mine_a = und_a && rank_a >= base && rank_a < base + (uint32_t)CAP;
+        const bool mine_b = BPL == 2 && und_b && rank_b >= base && rank_b < base + (uint32_t)CAP;
+        if (mine_a) {
+            GuardEntry *e = &entries[rank_a - base];
+            row1_deposit<BPL>(e, v, 0);
+            e->hi = hi_a; e->lo = 0u; e->nb = block_budget(first_a, n_bits, n);
+        }
+        if (mine_b) {
+            GuardEntry *e = &entries[rank_b - base];
+            row1_deposit<BPL>(e, v, 1);
+            e->hi = hi_b; e->lo = 0u; e->nb = block_budget(first_a + n, n_bits, n);
+        }
+        wave_lds_fence();
+        const uint32_t todo = min(total - base, (uint32_t)CAP);
+        for (uint32_t first = 0; first < todo; first += 8u) {
+            const uint32_t idx = first + (lane >> 3);
+            if (idx < todo) {
+                GuardEntry *e = &entries[idx];
+                guard_replay8<QM, 1>(e->px, e->hi, e->lo, e->nb, tile + (lane >> 3) * SVS_GUARD_TILE, lane & 7u, n, qp);
+            }
+        }
+        wave_lds_fence();
+        if (mine_a) row1_collect<BPL>(&entries[rank_a - base], v, 0);
+        if (mine_b) row1_collect<BPL>(&entries[rank_b - base], v, 1);
+        wave_lds_fence();   // the next round overwrites the entries
+    }
+    return total;
+}
+
+template <int QM, int BPL, int NFIX = 0>
+__global__ __launch_bounds__(SVS_WG, SVS_ROW1_MIN_WAVES) void embed_row1_kernel(const uint8_t *gray, uint8_t *stego, const Geometry g,
+                                                          const QimParams qp, const uint32_t *__restrict__ bits,
+                                                          const uint64_t bit_offset, const uint64_t n_bits,
+                                                          const uint32_t n_words SVS_REPLAY_COUNTER_PARAM) {
+    __shared__ GuardEntry entries[SVS_WG / 64][SVS_GUARD_CAP];
+    __shared__ float tiles[SVS_WG / 64][8 * SVS_GUARD_TILE];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t gblock = (tile_id(g.xcd_chunk) * (uint32_t)SVS_WG + threadIdx.x) * BPL;
+    const bool live = gblock < g.total_blocks;
+    const uint32_t gb = live ? gblock : g.total_blocks - (uint32_t)BPL;   // the host launches with total_blocks >= BPL (a multiple of BPL)
+    const uint32_t n = NFIX ? (uint32_t)NFIX : g.n_ac;
+    const int64_t off = block_offset(gb, g);
+    typename RowVec<BPL>::type v[8];
+    load_rows<BPL>(gray + off, g.row_pitch, v);
+    const uint64_t first = (uint64_t)gb * n;   // stream index of this lane's first bit
+    bool und_a = false, und_b = false, clip = false;
+    uint32_t hi_a = 0, hi_b = 0;
+    ColumnDeltas ca = {0u, 0u, 0u, 0u}, cb = {0u, 0u, 0u, 0u};
+    if (live && first < n_bits) {
+        const uint64_t q = payload_qword(bits, n_words, bit_offset + first);
+        const uint32_t sh = (uint32_t)((bit_offset + first) & 31u);
+        hi_a = window32(q, sh);
+        uint32_t flags;
+        {
+            uint32_t rx[8], ry[8];
+            row1_block<BPL>(v, 0, rx, ry);
+            flags = guard_decide_int<QM, NFIX>(rx, ry, n, block_budget(first, n_bits, n), hi_a, qp, ca);
+            und_a = (flags & SVS_ROW1_UNDECIDED) != 0;
+            if (und_a) { ca.e_lo = 0u; ca.o_lo = 0u; ca.e_hi = 0u; ca.o_hi = 0u; }   // keeps its original pixels for the replay
+        }
+        clip = flags == SVS_ROW1_MAY_CLIP;
+        if constexpr (BPL == 2) {
+            SVS_SCHED_FENCE();   // one block at a time
+            hi_b = window32(q, sh + n);
+            uint32_t rx[8], ry[8];
+            row1_block<BPL>(v, 1, rx, ry);
+            // a budget of 0 (only the lane the payload ends in can see it) leaves block B as it is: all its deltas are 0
+            flags = guard_decide_int<QM, NFIX>(rx, ry, n, block_budget(first + n, n_bits, n), hi_b, qp, cb);
+            und_b = (flags & SVS_ROW1_UNDECIDED) != 0;
+            if (und_b) { cb.e_lo = 0u; cb.o_lo = 0u; cb.e_hi = 0u; cb.o_hi = 0u; }
+            clip = clip || flags == SVS_ROW1_MAY_CLIP;
+        }
+    }
+    SVS_SCHED_FENCE();
+    // The stores (every lane: the deltas of a lane without payload are 0).  Wave-uniform: when some block of the wave could
+    // clip at 0 / 255, all of them take the saturating form - same bytes where nothing clips.
+    const bool clip_wave = SVS_ROW1_CLIP_PATH && __ballot(clip) != 0;
+    {
+        const uint32_t keep = clip_wave ? 0u : 0xffffffffu;
+        const uint32_t a0 = packed_addend(ca.e_lo, ca.o_lo) & keep, a1 = packed_addend(ca.e_hi, ca.o_hi) & keep;
+        const uint32_t b0 = packed_addend(cb.e_lo, cb.o_lo) & keep, b1 = packed_addend(cb.e_hi, cb.o_hi) & keep;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            v[r].x += a0; v[r].y += a1;
+            if constexpr (BPL == 2) { v[r].z += b0; v[r].w += b1; }
+        }
+    }
+    if (clip_wave) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            v[r].x = add_clip_dword(v[r].x, ca.e_lo, ca.o_lo);
+            v[r].y = add_clip_dword(v[r].y, ca.e_hi, ca.o_hi);
+            if constexpr (BPL == 2) {
+                v[r].z = add_clip_dword(v[r].z, cb.e_lo, cb.o_lo);
+                v[r].w = add_clip_dword(v[r].w, cb.e_hi, cb.o_hi);
+            }
+            SVS_SCHED_FENCE();   // row by row: scheduled for latency, this rare path would set the kernel's register count
+        }
+    }
+    const uint32_t redone = row1_phase2<QM, BPL, SVS_GUARD_CAP>(&entries[wave][0], &tiles[wave][0], lane, n, qp, n_bits, und_a, und_b, first,
+                                                                hi_a, hi_b, v);
+#if defined(SVS_EXPERIMENTS)
+    if (replay_counter != nullptr && redone != 0 && lane == 0) atomicAdd(replay_counter, (unsigned long long)redone);
+#else
+    (void)redone;
+#endif
+    // past the budget: byte-identical copy (the reference's loops `break`, :130,:132)
+    if (live && (stego != gray || first < n_bits)) store_rows<BPL>(stego + off, g.row_pitch, v);
 }
 
 template <int U, int QM, int BPL = 1>
