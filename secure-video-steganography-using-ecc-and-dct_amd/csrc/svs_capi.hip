@@ -153,12 +153,14 @@ Tuning extract_tuning(int rows, const svs_planes *p, const void *a) {
     return t;
 }
 
-// default caps (workgroups of 256 threads per CU; 0 = whatever registers and LDS allow).  Round 3: none.  The one-row embed
-// kernel with two blocks per lane is register-limited to 4 workgroups per CU (100 VGPRs) and insensitive to anything above
-// (sweep 4..8: 1.637-1.648 ms); with one block per lane (odd block counts per row) it is fastest uncapped (8: 1.80 ms, 7: 1.83,
-// 6: 1.92, 5: 2.20; profiles/r03_ab_occupancy.txt).  Every extract kernel, the embed kernels with more rows, the exact kernels
-// and a plain copy have always been fastest uncapped (tools/occupancy_sweep.sh).
-uint32_t embed_wg_per_cu(int rows, int bpl) { (void)rows; (void)bpl; return 0u; }
+// default caps (workgroups of 256 threads per CU = waves per SIMD; 0 = whatever registers and LDS allow).  Round 6, the
+// integer-domain one-row embed kernel (66 - 71 VGPRs: 7 waves per SIMD uncapped): measured with pure copies, the rate of this
+// access pattern falls - and its dependence on where the buffers were placed grows - with the BYTES IN FLIGHT per SIMD (rows per
+// lane x waves: 8 x 4 behaves like 16 x 2 and 4 x 8, profiles/r06_stream_probe.txt); the kernel is fastest at 4 - 5 waves with
+// two blocks per lane (1.52 / 1.61 ms per 600 x 4K on fast / slow placements against 1.55 - 1.70 uncapped, the same at n = 1, 7
+// and at 1080p: profiles/r06_place_new_vs_old.txt, r06_caps.txt) and at 6 with one block per lane.  Every extract kernel, the
+// embed kernels with more rows, the exact kernels and a plain copy have always been fastest uncapped (tools/occupancy_sweep.sh).
+uint32_t embed_wg_per_cu(int rows, int bpl) { return rows == 1 ? (bpl == 2 ? 4u : 6u) : 0u; }
 uint32_t extract_wg_per_cu(int rows) { (void)rows; return 0; }
 
 // Measurement hook of the EXPERIMENTS library only (svs_guard_counter_set): a device counter the streaming embed launches add

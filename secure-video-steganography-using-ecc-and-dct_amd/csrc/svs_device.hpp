@@ -962,34 +962,41 @@ __device__ __forceinline__ uint32_t row1_phase2(GuardEntry *entries, float *tile
     return total;
 }
 
-template <int QM, int BPL, int NFIX = 0>
-__global__ __launch_bounds__(SVS_WG, SVS_ROW1_MIN_WAVES) void embed_row1_kernel(const uint8_t *gray, uint8_t *stego, const Geometry g,
-                                                          const QimParams qp, const uint32_t *__restrict__ bits,
-                                                          const uint64_t bit_offset, const uint64_t n_bits,
-                                                          const uint32_t n_words SVS_REPLAY_COUNTER_PARAM) {
-    __shared__ GuardEntry entries[SVS_WG / 64][SVS_GUARD_CAP];
-    __shared__ float tiles[SVS_WG / 64][8 * SVS_GUARD_TILE];
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    const uint32_t gblock = (tile_id(g.xcd_chunk) * (uint32_t)SVS_WG + threadIdx.x) * BPL;
-    const bool live = gblock < g.total_blocks;
-    const uint32_t gb = live ? gblock : g.total_blocks - (uint32_t)BPL;   // the host launches with total_blocks >= BPL (a multiple of BPL)
+// what the lanes of a launch share (kernel arguments, in SGPRs)
+struct Row1Args {
+    const uint8_t *gray;
+    uint8_t *stego;
+    const uint32_t *bits;
+    uint64_t bit_offset, n_bits;
+    uint32_t n_words;
+};
+
+// lanes past the end of the batch shadow its last block(s): they load and compute like everybody else, and never store
+template <int BPL>
+__device__ __forceinline__ uint32_t row1_shadow(uint32_t gblock, const Geometry &g, bool &live) {
+    live = gblock < g.total_blocks;
+    return live ? gblock : g.total_blocks - (uint32_t)BPL;   // the host launches with total_blocks >= BPL (a multiple of BPL)
+}
+
+// phases 1-3 for the rows `v` of global block(s) gb (already loaded from gray + off): decide / apply, exact replay of the
+// wave's undecided blocks, store.
+template <int QM, int BPL, int NFIX>
+__device__ __forceinline__ uint32_t row1_process(typename RowVec<BPL>::type (&v)[8], uint32_t gb, bool live, int64_t off, uint64_t q,
+                                                 const Geometry &g, const QimParams &qp, const Row1Args &a, GuardEntry *entries,
+                                                 float *tile, uint32_t lane) {
     const uint32_t n = NFIX ? (uint32_t)NFIX : g.n_ac;
-    const int64_t off = block_offset(gb, g);
-    typename RowVec<BPL>::type v[8];
-    load_rows<BPL>(gray + off, g.row_pitch, v);
     const uint64_t first = (uint64_t)gb * n;   // stream index of this lane's first bit
     bool und_a = false, und_b = false, clip = false;
     uint32_t hi_a = 0, hi_b = 0;
     ColumnDeltas ca = {0u, 0u, 0u, 0u}, cb = {0u, 0u, 0u, 0u};
-    if (live && first < n_bits) {
-        const uint64_t q = payload_qword(bits, n_words, bit_offset + first);
-        const uint32_t sh = (uint32_t)((bit_offset + first) & 31u);
+    if (live && first < a.n_bits) {
+        const uint32_t sh = (uint32_t)((a.bit_offset + first) & 31u);
         hi_a = window32(q, sh);
         uint32_t flags;
         {
             uint32_t rx[8], ry[8];
             row1_block<BPL>(v, 0, rx, ry);
-            flags = guard_decide_int<QM, NFIX>(rx, ry, n, block_budget(first, n_bits, n), hi_a, qp, ca);
+            flags = guard_decide_int<QM, NFIX>(rx, ry, n, block_budget(first, a.n_bits, n), hi_a, qp, ca);
             und_a = (flags & SVS_ROW1_UNDECIDED) != 0;
             if (und_a) { ca.e_lo = 0u; ca.o_lo = 0u; ca.e_hi = 0u; ca.o_hi = 0u; }   // keeps its original pixels for the replay
         }
@@ -1000,7 +1007,7 @@ __global__ __launch_bounds__(SVS_WG, SVS_ROW1_MIN_WAVES) void embed_row1_kernel(
             uint32_t rx[8], ry[8];
             row1_block<BPL>(v, 1, rx, ry);
             // a budget of 0 (only the lane the payload ends in can see it) leaves block B as it is: all its deltas are 0
-            flags = guard_decide_int<QM, NFIX>(rx, ry, n, block_budget(first + n, n_bits, n), hi_b, qp, cb);
+            flags = guard_decide_int<QM, NFIX>(rx, ry, n, block_budget(first + n, a.n_bits, n), hi_b, qp, cb);
             und_b = (flags & SVS_ROW1_UNDECIDED) != 0;
             if (und_b) { cb.e_lo = 0u; cb.o_lo = 0u; cb.e_hi = 0u; cb.o_hi = 0u; }
             clip = clip || flags == SVS_ROW1_MAY_CLIP;
@@ -1032,16 +1039,41 @@ __global__ __launch_bounds__(SVS_WG, SVS_ROW1_MIN_WAVES) void embed_row1_kernel(
             SVS_SCHED_FENCE();   // row by row: scheduled for latency, this rare path would set the kernel's register count
         }
     }
-    const uint32_t redone = row1_phase2<QM, BPL, SVS_GUARD_CAP>(&entries[wave][0], &tiles[wave][0], lane, n, qp, n_bits, und_a, und_b, first,
-                                                                hi_a, hi_b, v);
+    const uint32_t redone = row1_phase2<QM, BPL, SVS_GUARD_CAP>(entries, tile, lane, n, qp, a.n_bits, und_a, und_b, first, hi_a, hi_b, v);
+    // past the budget: byte-identical copy (the reference's loops `break`, :130,:132)
+    if (live && (a.stego != a.gray || first < a.n_bits)) store_rows<BPL>(a.stego + off, g.row_pitch, v);
+    return redone;
+}
+
+template <int QM, int BPL, int NFIX = 0>
+__global__ __launch_bounds__(SVS_WG, SVS_ROW1_MIN_WAVES) void embed_row1_kernel(const uint8_t *gray, uint8_t *stego, const Geometry g,
+                                                          const QimParams qp, const uint32_t *__restrict__ bits,
+                                                          const uint64_t bit_offset, const uint64_t n_bits,
+                                                          const uint32_t n_words SVS_REPLAY_COUNTER_PARAM) {
+    __shared__ GuardEntry entries[SVS_WG / 64][SVS_GUARD_CAP];
+    __shared__ float tiles[SVS_WG / 64][8 * SVS_GUARD_TILE];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    bool live;
+    const uint32_t gb = row1_shadow<BPL>((tile_id(g.xcd_chunk) * (uint32_t)SVS_WG + threadIdx.x) * BPL, g, live);
+    const int64_t off = block_offset(gb, g);
+    typename RowVec<BPL>::type v[8];
+    load_rows<BPL>(gray + off, g.row_pitch, v);
+    const Row1Args a{gray, stego, bits, bit_offset, n_bits, n_words};
+    const uint32_t n = NFIX ? (uint32_t)NFIX : g.n_ac;
+    uint64_t q = 0;
+    if (live && (uint64_t)gb * n < n_bits) q = payload_qword(bits, n_words, bit_offset + (uint64_t)gb * n);
+    const uint32_t redone = row1_process<QM, BPL, NFIX>(v, gb, live, off, q, g, qp, a, &entries[wave][0], &tiles[wave][0], lane);
 #if defined(SVS_EXPERIMENTS)
     if (replay_counter != nullptr && redone != 0 && lane == 0) atomicAdd(replay_counter, (unsigned long long)redone);
 #else
     (void)redone;
 #endif
-    // past the budget: byte-identical copy (the reference's loops `break`, :130,:132)
-    if (live && (stego != gray || first < n_bits)) store_rows<BPL>(stego + off, g.row_pitch, v);
 }
+
+// (Round 6 also ran this kernel as a PERSISTENT, software-pipelined loop - few workgroups per CU, each loading the rows of its
+// next tile before it computes on the current one, so that the bytes in flight stay low and constant: correct, and slower on
+// every placement, 1.77 - 1.95 ms per 600 x 4K against 1.58 - 1.62, even with the arithmetic skipped: profiles/r06_stream_pipeline.txt.
+// What the one-shot launch has and the loop has not is the hardware's own pacing: a workgroup starts when another one ends.)
 
 template <int U, int QM, int BPL = 1>
 __global__ __launch_bounds__(SVS_WG) void extract_exact_kernel(const uint8_t *__restrict__ gray, const Geometry g,

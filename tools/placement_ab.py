@@ -22,13 +22,20 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--pairs", type=int, default=6); ap.add_argument("--burst", type=int, default=8); ap.add_argument("--rounds", type=int, default=3)
 ap.add_argument("--n-ac", type=int, default=3)
 ap.add_argument("--chunks", default="", help="comma list of further SVS_EMBED_XCD_CHUNK values (runs of that many tiles per XCD)")
+ap.add_argument("--cfg", action="append", default=[], help="NAME=LIB[:ENV=V[,ENV=V...]] - replaces the built-in configuration list; LIB = base | exp | "
+                "a file name under lib/variants (flags 0 for a library of an earlier round); ENV PATCOPY=1 launches with an empty payload "
+                "(the kernel's own access pattern, arithmetic skipped)")
 a = ap.parse_args()
 
 
 def load(name, hooks=False):
     lib = C.CDLL(os.path.join(PKG, "lib", name))
     for nm, (res, args) in {**native.SIGNATURES, **(EXPERIMENT_HOOKS if hooks else {})}.items():
-        fn = getattr(lib, nm); fn.restype, fn.argtypes = res, args
+        try:
+            fn = getattr(lib, nm)
+        except AttributeError:      # a library of an earlier round lacks the newer entry points
+            continue
+        fn.restype, fn.argtypes = res, args
     return lib
 
 
@@ -41,6 +48,16 @@ for v in (() if a.chunks else ("nosc1", "plain")):
     p = os.path.join(PKG, "lib", "variants", f"libsvsdct_{v}.so")
     if os.path.exists(p):
         configs.append((v, load(f"variants/libsvsdct_{v}.so"), {}))
+if a.cfg:
+    configs = []
+    for spec in a.cfg:
+        name, rest = spec.split("=", 1)
+        libname, _, envs = rest.partition(":")
+        lib = base if libname == "base" else exp if libname == "exp" else load(f"variants/{libname}")
+        env = dict(kv.split("=") for kv in envs.split(",") if kv)
+        if libname not in ("base", "exp") and "_r0" in libname:
+            env["FLAGS"] = "0"
+        configs.append((name, lib, env))
 torch.cuda.set_device(0)
 assert base.svs_init(0) == 0
 F, H, W, n, delta = 600, 2160, 3840, a.n_ac, 8.0
@@ -59,6 +76,9 @@ done = C.c_uint64()
 
 
 def burst(lib, env, g, s, copy=False):
+    env = dict(env)
+    flags = int(env.pop("FLAGS", "2"))
+    nbits = 0 if env.pop("PATCOPY", "0") == "1" else cap
     for k, v in env.items():
         os.environ[k] = v
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(a.burst + 1)]
@@ -67,7 +87,7 @@ def burst(lib, env, g, s, copy=False):
         if copy:
             assert exp.svs_ref_copy_dev(g, s, size, 3, st) == 0
         else:
-            assert lib.svs_embed_dev(g, s, C.byref(planes), delta, n, pay.data_ptr(), 0, cap, 2, C.byref(done), st) == 0
+            assert lib.svs_embed_dev(g, s, C.byref(planes), delta, n, pay.data_ptr(), 0, nbits, flags, C.byref(done), st) == 0
         ev[i + 1].record()
     torch.cuda.synchronize()
     for k in env:

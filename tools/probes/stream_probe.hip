@@ -1,0 +1,98 @@
+// stream_probe.hip - round 6: which property of the one-row embed kernel's access pattern makes it sensitive to where its two
+// buffers were placed, when a linear copy of the same bytes is not?  Pure copies of a 600 x 2160 x 3840 byte batch in which a
+// lane moves R rows of 16 bytes, rows one frame row (3840 B) apart:
+//     R = 8 is the embed kernel's pattern (two adjacent 8x8 blocks per lane), R = 1 the linear copy, R = 2, 4 in between;
+//     tile map: identity, or one contiguous eighth of the grid per XCD (the embed kernel's);
+//     order: all R loads, then all R stores (the kernel's) or row by row;
+//     cap: workgroups per CU (= waves per SIMD) through unused dynamic LDS.
+// Every configuration runs on the same P buffer pairs (hipMalloc, all resident): median ms per launch in bursts.
+// Build: hipcc --offload-arch=gfx950 -O3 -o tools/probes/stream_probe tools/probes/stream_probe.hip ; run: tools/probes/stream_probe [pairs]
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+constexpr uint32_t PITCH = 3840, STRIPS = PITCH / 16;
+constexpr uint64_t ROWS = 600ull * 2160ull, BYTES = ROWS * PITCH;
+
+__device__ __forceinline__ uint32_t tile_of(uint32_t map) {
+    const uint32_t i = blockIdx.x;
+    if (map == 0) return i;
+    const uint32_t n = gridDim.x, q = n / 8u, r = n % 8u, x = i % 8u;
+    return (x < r ? x * (q + 1u) : r * (q + 1u) + (x - r) * q) + i / 8u;
+}
+
+template <int R, int ORDER>
+__global__ __launch_bounds__(256) void rows_kernel(const uint8_t *src, uint8_t *dst, uint32_t map, uint32_t lanes_total, uint32_t never) {
+    extern __shared__ uint32_t pad[];
+    if (never == 0x12345678u) pad[threadIdx.x] = 1;
+    const uint32_t L = tile_of(map) * 256u + threadIdx.x;
+    if (L >= lanes_total) return;
+    const uint32_t grp = L / STRIPS, s = L - grp * STRIPS;
+    const int64_t off = (int64_t)grp * R * PITCH + s * 16;
+    u32x4 v[R];
+    if constexpr (ORDER == 0) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) v[r] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(src + off + r * (int64_t)PITCH));
+#pragma unroll
+        for (int r = 0; r < R; ++r) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(dst + off + r * (int64_t)PITCH), "v"(v[r]) : "memory");
+    } else {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            v[r] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(src + off + r * (int64_t)PITCH));
+            asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(dst + off + r * (int64_t)PITCH), "v"(v[r]) : "memory");
+        }
+    }
+}
+
+struct Cfg { const char *name; int R, order, map, cap; };
+
+template <int R, int ORDER>
+void launch(const uint8_t *s, uint8_t *d, int map, int cap) {
+    const uint32_t lanes = (uint32_t)(BYTES / (16ull * R));
+    const uint32_t lds = cap ? ((160u * 1024u / cap) & ~255u) : 0u;
+    hipLaunchKernelGGL((rows_kernel<R, ORDER>), dim3((lanes + 255) / 256), dim3(256), lds, 0, s, d, (uint32_t)map, lanes, 0u);
+}
+void go(const Cfg &c, const uint8_t *s, uint8_t *d) {
+#define GO(RR) if (c.R == RR) { if (c.order) launch<RR, 1>(s, d, c.map, c.cap); else launch<RR, 0>(s, d, c.map, c.cap); }
+    GO(1) GO(2) GO(4) GO(8) GO(16)
+#undef GO
+}
+
+int main(int argc, char **argv) {
+    const int pairs = argc > 1 ? atoi(argv[1]) : 4, burst = 7;
+    std::vector<std::pair<uint8_t *, uint8_t *>> bufs;
+    for (int k = 0; k < pairs; ++k) {
+        uint8_t *a, *b;
+        CK(hipMalloc(&a, BYTES)); CK(hipMalloc(&b, BYTES));
+        CK(hipMemset(a, 17 + k, BYTES));
+        bufs.push_back({a, b});
+    }
+    const Cfg cfgs[] = {
+        {"R1 identity", 1, 0, 0, 0}, {"R1 eighth", 1, 0, 1, 0}, {"R2 eighth", 2, 0, 1, 0}, {"R4 eighth", 4, 0, 1, 0},
+        {"R8 eighth", 8, 0, 1, 0}, {"R8 eighth cap4", 8, 0, 1, 4}, {"R8 eighth cap5", 8, 0, 1, 5}, {"R8 identity cap4", 8, 0, 0, 4},
+        {"R8 eighth rowwise", 8, 1, 1, 0}, {"R8 eighth rowwise cap4", 8, 1, 1, 4}, {"R4 eighth cap4", 4, 0, 1, 4}, {"R4 eighth cap8", 4, 0, 1, 8},
+        {"R2 eighth cap8", 2, 0, 1, 8}, {"R16 eighth cap4", 16, 0, 1, 4}, {"R16 eighth cap2", 16, 0, 1, 2}, {"R1 eighth cap4", 1, 0, 1, 4},
+    };
+    hipEvent_t ev[16];
+    for (auto &e : ev) CK(hipEventCreate(&e));
+    printf("# median ms per copy of %.3f GB (read) + the same written; %d placements\n", BYTES / 1e9, pairs);
+    for (const Cfg &c : cfgs) {
+        printf("%-24s", c.name);
+        for (auto &p : bufs) {
+            CK(hipEventRecord(ev[0]));
+            for (int i = 0; i < burst; ++i) { go(c, p.first, p.second); CK(hipEventRecord(ev[i + 1])); }
+            CK(hipDeviceSynchronize());
+            std::vector<float> t;
+            for (int i = 1; i < burst; ++i) { float ms; CK(hipEventElapsedTime(&ms, ev[i], ev[i + 1])); t.push_back(ms); }
+            std::sort(t.begin(), t.end());
+            printf("  %.4f", t[t.size() / 2]);
+        }
+        printf("\n");
+    }
+    return 0;
+}
