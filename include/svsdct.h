@@ -103,9 +103,10 @@ int svs_init(int device);
 /* Name of the architecture the device reports, e.g. "gfx950". */
 int svs_device_arch(int device, char *buf, size_t buf_len);
 /* Releases the CALLING THREAD's staging context of the host-pointer entry points (svs_embed, svs_extract, svs_embed_bgr,
- * svs_extract_bgr, svs_embed_str, svs_extract_str): two streams and grow-only device buffers as large as the largest call the
- * thread has made.  A thread's context is also released when the thread exits; calling any host-pointer entry point
- * afterwards simply builds a new one.  The *_dev entry points keep nothing. */
+ * svs_extract_bgr, svs_embed_str, svs_extract_str): two streams and device buffers sized by the calls the thread makes (a
+ * buffer above 64 MB that is more than four times what a call needs is given back at that call).  A thread's context is also
+ * released when the thread exits; calling any host-pointer entry point afterwards simply builds a new one.  The *_dev entry
+ * points keep nothing. */
 int svs_shutdown(void);
 
 /* ---- device memory / stream helpers for callers that do not bring their own ------------- */
@@ -157,12 +158,17 @@ int svs_embed(const uint8_t *gray, uint8_t *stego, const svs_planes *planes,
 /* The same call in the reference operator's own types (config_and_setup.py:106-109,172): the payload is `bit_payload_segment`,
  * a string of '0' / '1' characters (one character per bit, no terminator needed), and the operator's first return value - the
  * gray frame before embedding, as an array of its own (:113-114) - is produced as well.
- *   bits_ascii, n_chars : n_chars characters are available, min(n_chars, capacity) are read - a frame loop may hand over the
+ *   bits_ascii, n_chars : n_chars characters are available, min(n_chars, capacity) are read (each must be '0' or '1':
+ *                         SVS_ERR_INVALID_ARG otherwise - other characters have no pinned meaning in the reference) - a frame loop may hand over the
  *                         whole remaining payload as the reference does (embed_process.py:116-121) - and are packed on the
  *                         device.  n_chars > 0 with nothing embeddable (delta <= 0, n_ac <= 0) still round-trips every block,
  *                         n_chars = 0 (or NULL) copies the frames, as in the reference (:124-126).
- *   gray_ref_out        : NULL, or a buffer of the planes' geometry that receives a copy of `gray` (pixel bytes only).  The
- *                         calling thread makes the copy while the GPU works, so it costs the call nothing. */
+ *   gray_ref_out        : NULL, or a buffer of the planes' geometry that receives a copy of `gray` (pixel bytes only): the
+ *                         frames BEFORE embedding, also when stego aliases gray (in-place embedding - the copy is then made
+ *                         before the first download; otherwise the calling thread makes it while the GPU works).  It may be
+ *                         `gray` itself (no copy); it must not overlap `stego`, nor overlap `gray` partially
+ *                         (SVS_ERR_INVALID_ARG).  The up / down overlap of the call needs page-locked stego memory
+ *                         (svs_host_alloc): a pageable download blocks the calling thread. */
 int svs_embed_str(const uint8_t *gray, uint8_t *gray_ref_out, uint8_t *stego, const svs_planes *planes,
                   double delta, int n_ac, const char *bits_ascii, uint64_t n_chars,
                   uint32_t flags, uint64_t *n_embedded);

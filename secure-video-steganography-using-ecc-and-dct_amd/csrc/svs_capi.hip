@@ -195,7 +195,7 @@ int launch_embed(int rows, uint64_t total, hipStream_t st, const uint8_t *gray, 
         }
     }
     if (rows < 1 || rows > 2) return fail(SVS_ERR_INVALID_ARG, "internal: rows=%d, %d blocks per lane", rows, BPL);
-    if (rows == 1 && knob("SVS_ROW1_OLD", 0) == 0) {   // one coefficient row: the integer-domain kernel (round 6)
+    if (rows == 1) {   // one coefficient row: the integer-domain kernel (round 6; the round-5 kernel it replaced: commit a377b8d, experiments library, SVS_ROW1_OLD=1)
         if (g.n_ac == 3 && knob("SVS_FIXED_N", 1) != 0)   // BASELINE configs[2]: "3 AC coeffs/block"
             hipLaunchKernelGGL((svs::embed_row1_kernel<QM, BPL, 3>), grid, dim3(SVS_WG), lds_pad, st, gray, stego, g, qp, bits, bit_offset,
                                n_bits, n_words SVS_COUNTER_ARG);
@@ -206,23 +206,17 @@ int launch_embed(int rows, uint64_t total, hipStream_t st, const uint8_t *gray, 
         return SVS_OK;
     }
     if constexpr (BPL == 2) {
-        if (rows == 1)
-            hipLaunchKernelGGL((svs::embed_kernel<1, QM, 2>), grid, dim3(SVS_WG), lds_pad, st, gray, stego, g, qp, bits, bit_offset, n_bits,
-                               n_words SVS_COUNTER_ARG);
 #if SVS_U2_BPL == 2   // A/B build only: two adjacent blocks per lane with a joint replay need 150 VGPRs (3 waves per SIMD) and end
                       // level with one block per lane (2.57 vs 2.57 ms per 600 x 4K, profiles/r04_ab_two_row.txt)
-        else if (g.n_ac == 10)
+        if (g.n_ac == 10)
             hipLaunchKernelGGL((svs::embed_kernel<2, QM, 2, 10>), grid, dim3(SVS_WG), lds_pad, st, gray, stego, g, qp, bits, bit_offset, n_bits,
                                n_words SVS_COUNTER_ARG);
         else
             hipLaunchKernelGGL((svs::embed_kernel<2, QM, 2>), grid, dim3(SVS_WG), lds_pad, st, gray, stego, g, qp, bits, bit_offset, n_bits,
                                n_words SVS_COUNTER_ARG);
 #else
-        else return fail(SVS_ERR_INVALID_ARG, "internal: rows=%d with two blocks per lane", rows);
+        return fail(SVS_ERR_INVALID_ARG, "internal: rows=%d with two blocks per lane", rows);
 #endif
-    } else if (rows == 1) {
-        hipLaunchKernelGGL((svs::embed_kernel<1, QM, 1>), grid, dim3(SVS_WG), lds_pad, st, gray, stego, g, qp, bits, bit_offset, n_bits,
-                           n_words SVS_COUNTER_ARG);
     } else {
         hipLaunchKernelGGL((svs::embed_kernel<2, QM, 1>), grid, dim3(SVS_WG), lds_pad, st, gray, stego, g, qp, bits, bit_offset, n_bits,
                            n_words SVS_COUNTER_ARG);
@@ -380,10 +374,11 @@ constexpr int kStageStreams = 2;      // st[0] = up (H2D copies + kernels), st[1
 constexpr int kChunkEvents = 32;      // "kernel of chunk k done" events, reused round-robin (a stream wait captures the
                                       // event's record at the time of the call, so re-recording one later is safe)
 
-struct Grow {   // grow-only device buffer
+struct Grow {   // device buffer of a staging context: grows on demand, shrinks when a call needs far less than it holds
     void *p = nullptr;
     size_t cap = 0;
 };
+constexpr size_t kStageKeepBytes = (size_t)64 << 20;   // a buffer up to this size is kept whatever the next call needs
 
 struct HostStage {
     int device = -1;
@@ -429,9 +424,11 @@ int stage_acquire(HostStage **out) {
 }
 
 int stage_reserve(Grow &g, size_t bytes) {
-    if (bytes <= g.cap) return SVS_OK;
-    if (g.p) { SVS_HIP(hipFree(g.p)); g.p = nullptr; g.cap = 0; }
     const size_t want = (bytes + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);   // whole 2 MB pages
+    // enough, and not grossly more: a long-lived thread that once staged a multi-GB batch does not keep that HBM for good
+    //  - a buffer above 64 MB that is more than four times what this call needs is given back first
+    if (bytes <= g.cap && !(g.cap > kStageKeepBytes && g.cap / 4 > want)) return SVS_OK;
+    if (g.p) { SVS_HIP(hipFree(g.p)); g.p = nullptr; g.cap = 0; }
     SVS_HIP(hipMalloc(&g.p, want));
     g.cap = want;
     return SVS_OK;
@@ -835,6 +832,23 @@ static int stage_payload_ascii(HostStage &c, const char *bits_ascii, uint64_t us
     return SVS_OK;
 }
 
+static bool ranges_overlap(const void *a, const void *b, uint64_t span) {
+    const uintptr_t x = (uintptr_t)a, y = (uintptr_t)b;
+    return x < y + span && y < x + span;
+}
+
+// the operator's first return value - the gray frames before embedding as arrays of their own (config_and_setup.py:113-114,172)
+static void copy_gray_reference(uint8_t *dst, const uint8_t *gray, const svs_planes *planes, bool frames_packed, uint64_t span) {
+    if (frames_packed) {
+        memcpy(dst, gray, span);
+        return;
+    }
+    for (int32_t f = 0; f < planes->n_frames; ++f)
+        for (int32_t y = 0; y < planes->height; ++y)
+            memcpy(dst + (int64_t)f * planes->frame_pitch + (int64_t)y * planes->row_pitch,
+                   gray + (int64_t)f * planes->frame_pitch + (int64_t)y * planes->row_pitch, (size_t)planes->width);
+}
+
 // svs_embed (payload = packed MSB-first bits, indexed by bit_offset) and svs_embed_str (payload = n_bits '0' / '1' characters,
 // bit_offset = 0) share everything but the way the payload reaches the device
 static int embed_host(const uint8_t *gray, uint8_t *stego, uint8_t *gray_ref_out, const svs_planes *planes, double delta, int n_ac,
@@ -874,6 +888,10 @@ static int embed_host(const uint8_t *gray, uint8_t *stego, uint8_t *gray_ref_out
     uint8_t *d = static_cast<uint8_t *>(c.frames.p);
     uint64_t done_total = 0;
     int rc = SVS_OK;
+    // in-place embedding (stego overlaps gray) with a gray reference asked for: the reference must be taken BEFORE the first
+    // download lands in the source (a pageable download blocks, so it used to happen on every such call)
+    const bool ref_first = gray_ref_out && gray_ref_out != gray && ranges_overlap(gray, stego, span);
+    if (ref_first) copy_gray_reference(gray_ref_out, gray, planes, frames_packed, span);
     // one chunk (a frame below 8 MB): everything in order on one stream - no event, no second stream
     uint32_t n_chunks = 0;
     for_each_chunk(planes->n_frames, H, (size_t)rp, stage_chunk_bytes(span), [&](const Chunk &) { ++n_chunks; });
@@ -904,16 +922,9 @@ static int embed_host(const uint8_t *gray, uint8_t *stego, uint8_t *gray_ref_out
             }
         }
     });
-    // the operator's first return value - the gray frames before embedding as arrays of their own (config_and_setup.py:113-114,
-    // 172) - is copied by the calling thread HERE, while the streams work: everything is enqueued, the thread would only wait
-    if (!rc && gray_ref_out && gray_ref_out != gray) {
-        if (frames_packed) {
-            memcpy(gray_ref_out, gray, span);
-        } else {
-            for (int32_t f = 0; f < planes->n_frames; ++f)
-                for (int32_t y = 0; y < H; ++y) memcpy(gray_ref_out + (int64_t)f * fp + (int64_t)y * rp, gray + (int64_t)f * fp + (int64_t)y * rp, (size_t)W);
-        }
-    }
+    // the gray reference is copied by the calling thread HERE, while the streams work: everything is enqueued, the thread would
+    // only wait.  (Not when stego overlaps gray: the downloads would overwrite the source first - that copy was made above.)
+    if (!rc && gray_ref_out && gray_ref_out != gray && !ref_first) copy_gray_reference(gray_ref_out, gray, planes, frames_packed, span);
     rc = guard.done(rc);
     if (rc) return rc;
     if (n_embedded) *n_embedded = done_total;
@@ -925,10 +936,30 @@ int svs_embed(const uint8_t *gray, uint8_t *stego, const svs_planes *planes, dou
     return embed_host(gray, stego, nullptr, planes, delta, n_ac, bits_packed, nullptr, bit_offset, n_bits, flags, n_embedded);
 }
 
+// every character '0' or '1'?  One OR-reduction over the bytes (vectorised: about 0.05 ms per million characters)
+static bool ascii_bits_valid(const char *s, uint64_t n) {
+    uint8_t acc = 0;
+    for (uint64_t i = 0; i < n; ++i) acc |= (uint8_t)((uint8_t)s[i] ^ 0x30u);
+    return (acc & 0xfeu) == 0;
+}
+
 int svs_embed_str(const uint8_t *gray, uint8_t *gray_ref_out, uint8_t *stego, const svs_planes *planes, double delta, int n_ac,
                   const char *bits_ascii, uint64_t n_chars, uint32_t flags, uint64_t *n_embedded) {
     if (n_chars && !bits_ascii) return fail(SVS_ERR_INVALID_ARG, "bits pointer is NULL");
-    if (gray_ref_out && (gray_ref_out == stego)) return fail(SVS_ERR_INVALID_ARG, "gray_ref_out must not be the stego buffer");
+    // Only '0' / '1' characters have a pinned meaning: the reference takes int(ch) and sends anything that is not 1 down its
+    // "bit 0" branch unconditionally (config_and_setup.py:146-155) - a digit such as '3' then DECREMENTS every index, which is
+    // neither bit.  The characters that would be read (the front of the string, up to the capacity) are checked; others are refused.
+    if (n_chars) {
+        const uint64_t cap = svs_capacity_bits(planes, n_ac);
+        if (!ascii_bits_valid(bits_ascii, n_chars < cap ? n_chars : cap))
+            return fail(SVS_ERR_INVALID_ARG, "the payload must consist of '0' and '1' characters");
+    }
+    if (gray_ref_out && planes && planes->n_frames > 0 && planes->height > 0 && planes->width > 0) {
+        const uint64_t span = span_bytes(planes);
+        if (ranges_overlap(gray_ref_out, stego, span)) return fail(SVS_ERR_INVALID_ARG, "gray_ref_out must not overlap the stego buffer");
+        if (gray_ref_out != gray && ranges_overlap(gray_ref_out, gray, span))
+            return fail(SVS_ERR_INVALID_ARG, "gray_ref_out must be the gray buffer itself or not overlap it");
+    }
     return embed_host(gray, stego, gray_ref_out, planes, delta, n_ac, nullptr, bits_ascii ? bits_ascii : "", 0, n_chars, flags, n_embedded);
 }
 

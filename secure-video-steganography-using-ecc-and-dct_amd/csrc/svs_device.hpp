@@ -468,7 +468,7 @@ __global__ __launch_bounds__(SVS_WG, SVS_EXACT2_MIN_WAVES) void embed_exact_pair
 }
 
 // ---------------------------------------------------------------------------------------
-// EMBED, streaming kernel (n <= 15; flags 0 and SVS_EXACT_GUARDED, include/svsdct.h): one lane = BPL adjacent blocks, grid = ceil(total_blocks / (SVS_WG*BPL))
+// EMBED, streaming kernel (launched for two coefficient rows, n = 8..15, since round 6 - one row: embed_row1_kernel below; flags 0 and SVS_EXACT_GUARDED, include/svsdct.h): one lane = BPL adjacent blocks, grid = ceil(total_blocks / (SVS_WG*BPL))
 // workgroups of SVS_WG.  BPL = 2 (16-byte row accesses) needs an even number of blocks per row and 16-byte aligned rows
 // (the host checks) and is instantiated for one coefficient row only.
 // HBM traffic per block: 64 B read + 64 B written + n payload bits read - nothing else, whatever the content.
@@ -773,8 +773,7 @@ __global__ __launch_bounds__(SVS_WG, kEmbedMinWaves<U>) void embed_kernel(const 
                                                     uint8_t *stego, const Geometry g, const QimParams qp,
                                                     const uint32_t *__restrict__ bits, const uint64_t bit_offset,
                                                     const uint64_t n_bits, const uint32_t n_words SVS_REPLAY_COUNTER_PARAM) {
-    static_assert(U <= 2, "n <= 15 (svs_capi.hip: more coefficient rows run embed_exact_kernel in every mode)");
-    static_assert(NFIX == 0 || U == 2, "compile-time n: two coefficient rows only");
+    static_assert(U == 2, "n = 8..15 (svs_capi.hip: one coefficient row runs embed_row1_kernel, more rows embed_exact_kernel in every mode)");
     constexpr bool WGPOOL = U == 2 && BPL == 1 && SVS_U2_WGPOOL;
     constexpr bool PARKED = U == 2 && BPL == 1 && !WGPOOL && (SVS_U2_INPLACE == 2 || (SVS_U2_INPLACE == 1 && QM != QM_POW2));
     constexpr int CAP = WGPOOL ? SVS_GUARD_CAP_WG : SVS_GUARD_CAP;

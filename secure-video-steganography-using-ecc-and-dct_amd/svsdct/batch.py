@@ -169,6 +169,9 @@ def _ascii_address(text: str):
     character; PyUnicode_AsUTF8AndSize hands out that very buffer).  The reference's frame loop passes the whole remaining
     payload to every call (embed_process.py:116) - slicing or encoding it per frame would copy it per frame."""
     global _utf8_and_size
+    if not isinstance(text, str):
+        raise TypeError("the payload must be a str of '0' / '1' characters (bit_payload_segment of the reference operator); "
+                        "use embed_frames for arrays of bits")
     if _utf8_and_size is None:
         fn = C.pythonapi.PyUnicode_AsUTF8AndSize
         fn.restype, fn.argtypes = C.c_void_p, [C.py_object, C.POINTER(C.c_ssize_t)]

@@ -1,8 +1,9 @@
 """NumPy arrays in page-locked host memory, recycled.
 
 The host-pointer entry points of the C ABI (svs_embed / svs_extract ...) move a page-locked buffer with the DMA engines
-directly; pageable memory goes through the library's pinned staging rings (one more copy), and a FRESH pageable result array
-is worse still: every 4 KB page of it faults on first touch (an 8 MB stego frame = 2 025 faults per call of the reference's
+directly; pageable memory takes the HIP runtime's own staging (uploads at the same rate, downloads at half - a pageable
+download also blocks the calling thread, so the two-stream overlap of the call needs page-locked outputs; a staging ring of the
+library's own was measured and deleted, profiles/r05_stage_ring_ab.txt), and a FRESH pageable result array is worse still: every 4 KB page of it faults on first touch (an 8 MB stego frame = 2 025 faults per call of the reference's
 frame loop, embed_process.py:117-121).  So the arrays this package hands back to its callers - the stego frames, the gray
 reference copy the operator returns (config_and_setup.py:113-114,172) - come from `pinned_empty`: memory from svs_host_alloc
 wrapped as an ordinary `numpy.ndarray`.  When the last view of such an array is garbage-collected the buffer goes back to a

@@ -135,6 +135,14 @@ def ensure_device(device: int = 0) -> None:
     _current.device = device
 
 
+def release_thread_context() -> None:
+    """Give back the calling thread's staging context of the host-pointer entry points (svs_shutdown: two streams and the
+    device buffers the thread's calls grew); the next such call builds a new one.  The frame pipelines call it when they
+    close, so a worker thread that has processed a clip does not keep HBM for the rest of the process."""
+    if _lib is not None:
+        _lib.svs_shutdown()
+
+
 def device_arch(device: int = 0) -> str:
     buf = C.create_string_buffer(128)
     check(load().svs_device_arch(device, buf, len(buf)), "svs_device_arch")

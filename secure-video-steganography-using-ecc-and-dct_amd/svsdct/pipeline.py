@@ -147,6 +147,7 @@ class FramePipeline:
         if self._d_payload is not None:
             self.lib.svs_free(self._d_payload)
             self._d_payload = None
+        native.release_thread_context()      # the per-frame operator calls of this thread (first-frame PSNR pair, ...) grew one
 
     def __enter__(self):
         return self

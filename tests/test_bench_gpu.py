@@ -67,6 +67,24 @@ def test_strong_scaling_frames_divided_over_two_gloo_ranks():
     assert len(r["kernel_ms"]["per_rank"]["extract"]) == 2
 
 
+def test_gather_exit_rule_at_delta_4_and_with_a_swapped_slice():
+    """VERDICT r05 next #4.  delta = 4 (BASELINE configs[4]'s sweep): the reference itself loses 1.67 % of the bits, so the
+    gathered slices are NOT the payload - a correct gather must still pass (sender digests = received digests, exit 0).
+    A gather whose first two slices changed hands must end non-zero, at any delta."""
+    r = _bench("--gpus", "2", "--rehearse-gloo", "--delta", "4")
+    assert r["gather_ok"] is True and r["payload_bit_errors"] > 0 and r["gather_matches_payload"] is False
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("RANK", None)
+    env.pop("WORLD_SIZE", None)
+    for delta in ("8", "4"):
+        res = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--rehearse-gloo", "--inject-gather-swap",
+                              "--delta", delta, *SMALL], env=env, capture_output=True, text=True, timeout=600)
+        assert res.returncode != 0, res.stdout[-2000:]
+        line = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+        assert len(line) == 1 and json.loads(line[0])["gather_ok"] is False
+        assert "gathered bit stream" in res.stderr + res.stdout
+
+
 def test_refuses_to_start_ranks_under_a_profiler():
     env = dict(os.environ, ROCP_TOOL_LIBRARIES="/opt/rocm/lib/rocprofiler-sdk/librocprofiler-sdk-tool.so")
     env.pop("RANK", None)

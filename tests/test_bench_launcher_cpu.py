@@ -92,6 +92,46 @@ def test_exit_rule_follows_the_oracle_not_zero():
     assert bench.round_trip_verdict(None, 5, 64.0, 3) is None                    # large steps clip
 
 
+def test_a_wrong_gather_cannot_exit_zero_and_a_correct_one_cannot_fail_at_any_delta():
+    """the collective's exit rule is the senders' digests against what rank 0 received - fatal when they
+    differ, silent about the payload (at delta = 4 the reference itself loses 1.67 % of the bits)"""
+    import torch
+
+    import bench
+    ok = {"gpu_round_trip_bit_errors_on_sample": 0, "oracle_round_trip_bit_errors_on_sample": 0,
+          "gpu_extract_of_reference_stego_bit_mismatches": 0}
+    for delta in (4.0, 8.0, 16.0, 64.0):
+        assert bench.round_trip_verdict(None, 12345, delta, 3, gather_ok=False)          # a wrong gather is fatal everywhere
+        assert bench.round_trip_verdict(ok, 0, delta, 3, gather_ok=False)
+    assert bench.round_trip_verdict(None, 3891153, 4.0, 3, gather_ok=True) is None       # configs[4]'s delta = 4 leg: correct run passes
+    assert bench.round_trip_verdict(None, 0, 8.0, 3, gather_ok=True) is None
+    assert bench.round_trip_verdict(None, 0, 8.0, 3, gather_ok=None) is None
+    # the digest: equal for equal bytes, different when two slices change hands or a piece moves inside a slice
+    g = torch.Generator().manual_seed(7)
+    a = torch.randint(0, 256, (1003,), dtype=torch.uint8, generator=g)
+    b = torch.randint(0, 256, (1003,), dtype=torch.uint8, generator=g)
+    da, db = bench.stream_digest(a, 1000), bench.stream_digest(b, 1000)
+    assert torch.equal(da, bench.stream_digest(a.clone(), 1000)) and not torch.equal(da, db)
+    moved = a.clone()
+    moved[:8], moved[8:16] = a[8:16], a[:8]                                              # same multiset of words, other order
+    assert not torch.equal(da, bench.stream_digest(moved, 1000))
+    beyond = a.clone()
+    beyond[1001] ^= 0xff                                                                 # bytes past n_bytes do not count
+    assert torch.equal(da, bench.stream_digest(beyond, 1000))
+    flipped = a.clone()
+    flipped[999] ^= 1
+    assert not torch.equal(da, bench.stream_digest(flipped, 1000))
+
+
+def test_roofline_kernel_label_follows_the_launch_predicate():
+    """the label is derived from the predicate of csrc/svs_capi.hip, delta range included"""
+    import bench
+    assert bench.embed_kernel_label("guarded", 3, 8.0).startswith("embed_row1_kernel")
+    assert bench.embed_kernel_label("guarded", 10, 8.0).startswith("embed_kernel<2>")
+    for mode, n, delta in (("exact", 3, 8.0), ("guarded", 16, 8.0), ("guarded", 3, 0.1), ("guarded", 3, 8192.0), ("guarded", 63, 8.0)):
+        assert bench.embed_kernel_label(mode, n, delta).startswith("embed_exact_kernel"), (mode, n, delta)
+
+
 def test_documented_multi_gpu_commands_parse_and_plan():
     """the multi-GPU commands of the BASELINE configurations as README.md documents them are parsed by
     bench.py's own parser and dry-run through bench.job_plan (pure arithmetic, no GPU): contiguous shares that cover the clip

@@ -978,7 +978,7 @@ def _pinned(shape):
 
 @pytest.mark.parametrize("chunk_kb", [8, 32, 4096])
 def test_host_pointer_calls_chunked_staging_pitched_pinned_and_pageable(chunk_kb, monkeypatch):
-    """svs_embed / svs_extract move the batch in chunks over three streams of a per-thread context (csrc/svs_capi.hip).  With
+    """svs_embed / svs_extract move the batch in chunks over the two streams (one up, one down) of a per-thread context (csrc/svs_capi.hip).  With
     the experiments library's SVS_STAGE_CHUNK_KB the chunks become bands of 32 rows (8 KB), groups of three frames (32 KB) or
     the whole batch (4 MB) of a pitched five-frame clip with an odd block count per row; budgets that end in the first chunk,
     inside a later one, exactly on a chunk boundary and beyond the capacity; pageable and page-locked buffers on either side.
@@ -1045,6 +1045,43 @@ def test_host_pointer_calls_chunked_staging_pitched_pinned_and_pageable(chunk_kb
     assert exp.svs_shutdown() == 0                                        # the thread's context goes; the next call rebuilds it
     stego, used = batch.embed_frames(cover, delta, n_ac, synth.synthetic_bits(cap, seed=1))
     assert used == cap
+
+
+def test_in_place_embed_str_returns_the_frames_before_embedding():
+    """svs_embed_str with stego == gray (in-place embedding, which the header allows) and a gray
+    reference - the reference must hold the frames BEFORE embedding although the downloads overwrite the source.  Multi-chunk
+    geometry (3 x 4K: the product library moves each frame in two bands), pageable and page-locked memory.  Overlapping
+    reference buffers are refused."""
+    lib = native.load()
+    f, h, w, n_ac, delta = 3, 2160, 3840, 3, 8
+    cover = synth.synthetic_frames(f, h, w, seed=61)
+    cap = batch.capacity_bits(f, h, w, n_ac)
+    bits = synth.synthetic_bits(cap - 1234, seed=62)
+    text = batch.bits_to_str(bits).encode()
+    want, want_used = orc.batch_embed(cover, delta, bits, n_ac)
+    planes = Planes.contiguous(f, h, w)
+    used = C.c_uint64(0)
+    for pinned in (False, True):
+        buf = _pinned(f * h * w) if pinned else np.empty(f * h * w, np.uint8)
+        ref = _pinned(f * h * w) if pinned else np.empty(f * h * w, np.uint8)
+        buf[:] = cover.ravel()
+        ref[:] = 0x5A
+        rc = lib.svs_embed_str(buf.ctypes.data, ref.ctypes.data, buf.ctypes.data, C.byref(planes), float(delta), n_ac, text, len(text),
+                               native.SVS_EXACT_GUARDED, C.byref(used))
+        assert rc == 0, lib.svs_last_error()
+        assert used.value == want_used == bits.size
+        assert np.array_equal(buf.reshape(f, h, w), want), pinned
+        assert np.array_equal(ref.reshape(f, h, w), cover), f"gray reference holds stego pixels (pinned = {pinned})"
+    # gray_ref_out == gray is the no-copy form; a reference that overlaps stego, or gray partially, is refused
+    two = np.empty(2 * f * h * w, np.uint8)
+    two[:f * h * w] = cover.ravel()
+    a = two.ctypes.data
+    assert lib.svs_embed_str(a, a, a + f * h * w, C.byref(planes), float(delta), n_ac, text, len(text), native.SVS_EXACT_GUARDED, C.byref(used)) == 0
+    assert np.array_equal(two[f * h * w:].reshape(f, h, w), want)
+    assert lib.svs_embed_str(a, a + w, a + f * h * w, C.byref(planes), float(delta), n_ac, text, len(text), native.SVS_EXACT_GUARDED,
+                             C.byref(used)) == native.SVS_ERR_INVALID_ARG
+    assert lib.svs_embed_str(a, a + f * h * w - w, a + f * h * w, C.byref(planes), float(delta), n_ac, text, len(text), native.SVS_EXACT_GUARDED,
+                             C.byref(used)) == native.SVS_ERR_INVALID_ARG
 
 
 def test_host_pointer_calls_product_library_large_batches_and_shutdown():
@@ -1202,6 +1239,20 @@ def test_string_payload_entry_points_equal_the_packed_ones():
         assert text == batch.unpack_to_str(packed, n_bits)
     with pytest.raises(ValueError):
         batch.embed_frames_str(cover, 8, 3, "01\u20ac")                    # not a one-byte-per-character string
+    # characters other than '0' / '1' have no pinned meaning (the reference DECREMENTS the index for any digit but 1,
+    # whatever its parity) - refused by the library when they lie inside what would be read, ignored beyond the capacity
+    small = synth.synthetic_frames(1, 16, 16, seed=3)
+    cap16 = batch.capacity_bits(1, 16, 16, 3)
+    with pytest.raises(native.SvsNativeError):
+        batch.embed_frames_str(small, 8, 3, "0130")
+    with pytest.raises(native.SvsNativeError):
+        batch.embed_frames_str(small, 8, 3, "01 1")
+    ok = "01" * (cap16 // 2)
+    got, used = batch.embed_frames_str(small, 8, 3, ok + "xyz")           # read up to the capacity only, as the reference does
+    want, _ = batch.embed_frames_str(small, 8, 3, ok)
+    assert used == cap16 and np.array_equal(got, want)
+    with pytest.raises(TypeError):
+        batch.embed_frames_str(small, 8, 3, [0, 1, 1])
 
 
 def test_fused_colour_host_calls_in_bands_and_frame_groups():
