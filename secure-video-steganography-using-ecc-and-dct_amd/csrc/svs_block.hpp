@@ -153,7 +153,7 @@ template <int B>
 SVS_HD uint32_t put_pixel(float v, uint32_t old) {
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(SVS_NO_CVT_PK_U8)
     // v_cvt_pk_u8_f32 saturates to [0,255] and rounds to nearest even (measured on gfx950:
-    // profiles/r01_cvt_pk_u8_probe.json) - exact for the integer-valued input it gets here.
+    // profiles/history/r01_cvt_pk_u8_probe.json) - exact for the integer-valued input it gets here.
     return __builtin_amdgcn_cvt_pk_u8_f32(v, B, old);
 #else
     const float c = v < 0.0f ? 0.0f : (v > 255.0f ? 255.0f : v);

@@ -63,7 +63,7 @@ constexpr uint32_t knob(const char *, uint32_t dflt) { return dflt; }
 
 // Occupancy cap: unused dynamic LDS such that at most `wg_per_cu` workgroups fit the CU's 160 KB (0 = no cap).  The
 // streaming kernels run FASTER with fewer waves in flight than their register count allows (measured sweeps in
-// profiles/r01_ab_occupancy.txt): fewer concurrent row streams per CU.
+// profiles/history/r01_ab_occupancy.txt): fewer concurrent row streams per CU.
 uint32_t lds_pad_for(uint32_t wg_per_cu, uint32_t static_lds) {
     if (wg_per_cu == 0) return 0;
     const uint32_t per_wg = (160u * 1024u / wg_per_cu) & ~255u;
@@ -108,7 +108,7 @@ uint64_t span_bytes(const svs_planes *p) {
 
 using svs::rows_for;
 
-// ---- launch tuning (measured on MI355X, 600 x 4K frames; profiles/r01_ab_variants.txt) ----------------
+// ---- launch tuning (measured on MI355X, 600 x 4K frames; profiles/history/r01_ab_variants.txt) ----------------
 // * workgroup -> tile mapping (svs::tile_id): giving each XCD-group a contiguous eighth of the batch
 //   lifts the embed kernel ~+6..12 % (reads and writes of one XCD stay on neighbouring DRAM pages) and is
 //   never worse than the identity map; the read-only extract kernel at one coefficient row prefers runs of
@@ -143,7 +143,7 @@ Tuning embed_tuning(int rows, const svs_planes *p, const void *a, const void *b)
 }
 
 Tuning extract_tuning(int rows, const svs_planes *p, const void *a) {
-    // tile map of the read-only kernels (A/B sweeps: profiles/r01_ab_variants.txt, profiles/r02_ab_extract_chunk.txt): one
+    // tile map of the read-only kernels (A/B sweeps: profiles/history/r01_ab_variants.txt, profiles/history/r02_ab_extract_chunk.txt): one
     // coefficient row - runs of 32 tiles per XCD; two rows (n = 8..15) - the identity map (+6.7 % at 600 x 4K, +4.4 % at
     // 2 400 x 1080p over the contiguous eighth, equal at 300 x 1080p); more rows - VALU-bound, the map does not matter
     Tuning t{false, rows == 1 ? 32u : (rows == 2 ? 0u : kEighth)};
@@ -230,7 +230,7 @@ int launch_extract(int rows, uint64_t total, hipStream_t st, const uint8_t *gray
                    const svs::QimParams &qp, uint8_t *out, uint64_t out_bytes) {
     const dim3 grid((uint32_t)((total + SVS_WG * BPL - 1) / (SVS_WG * BPL)));
     // n = 10 (the reference GUI's default) has a compile-time-n instantiation of the extract kernel: +1..7 %
-    // (profiles/r01_ab_quant_exact.txt).  The same specialisation of the embed kernel measured SLOWER (-13 % at
+    // (profiles/history/r01_ab_quant_exact.txt).  The same specialisation of the embed kernel measured SLOWER (-13 % at
     // 600 x 4K, n = 10) and n = 3 gains nothing (HBM-bound), so those stay on the run-time-n kernels.
     const bool fixed_n = knob("SVS_FIXED_N", 1) != 0;   // experiment knob
     const uint32_t lds_pad = lds_pad_for(knob("SVS_EXTRACT_WG_PER_CU", extract_wg_per_cu(rows)), 18432);
@@ -666,7 +666,7 @@ int svs_embed_dev(const uint8_t *d_gray, uint8_t *d_stego, const svs_planes *pla
 #endif
     // SVS_EXACT_BPL=2 (experiment knob): exact arithmetic on two adjacent blocks per lane with every transform instruction
     // packed over the pair (embed_exact_pair_kernel).  Measured SLOWER than the one-block kernel (3.54 vs 3.16 ms at n = 3,
-    // 4.83 vs 3.38 ms at n = 10, profiles/r02_ab_exact_pair.txt): a v_pk_*_f32 costs two issue slots on this chip, so
+    // 4.83 vs 3.38 ms at n = 10, profiles/history/r02_ab_exact_pair.txt): a v_pk_*_f32 costs two issue slots on this chip, so
     // halving the instruction count buys nothing and the 256-register footprint costs occupancy.  Off by default.
     const bool exact_pair = rows_allow_two_blocks(planes, d_gray, d_stego) && knob("SVS_EXACT_BPL", 1) == 2;
     if (!streaming) {
@@ -755,7 +755,7 @@ int svs_extract_dev(const uint8_t *d_gray, const svs_planes *planes, double delt
         // the FAST kernels with two and more rows round c / delta by adding 1.5 * 2^23, which needs |c / delta| < 2^22
         if ((double)qp.delta_f < SVS_FAST_EXTRACT_DELTA_MIN) flags = SVS_EXACT_POCKETFFT;
         // With one coefficient row (n <= 7) the pocketfft-identical forward transform costs 0.2-3 % (the kernel stays
-        // HBM-bound; in-process A/B in profiles/r01_ab_quant_exact.txt), so FAST mode uses it too and extraction is
+        // HBM-bound; in-process A/B in profiles/history/r01_ab_quant_exact.txt), so FAST mode uses it too and extraction is
         // bit-identical to the reference for ANY input frame.  With more rows it costs ~17 % and stays opt-in.
         // SVS_FAST_EXTRACT_U1=1 (experiment knob) selects the FMA-factored forward instead.
 #if defined(SVS_EXPERIMENTS)
@@ -778,7 +778,7 @@ int svs_extract_dev(const uint8_t *d_gray, const svs_planes *planes, double delt
             rc = qm == svs::QM_POW2 ? launch_extract_exact<svs::QM_POW2>(rows, total, st, d_gray, g, qp, d_bits_packed_out, bytes, two_x)
                                     : launch_extract_exact<svs::QM_F32>(rows, total, st, d_gray, g, qp, d_bits_packed_out, bytes, two_x);
         } else if (qm == svs::QM_POW2)
-#if defined(SVS_EXPERIMENTS)   // two blocks per lane in the FMA-factored extract kernels: -3 % / +1.5 % (profiles/r02_ab_extract_bpl.txt), experiments library only
+#if defined(SVS_EXPERIMENTS)   // two blocks per lane in the FMA-factored extract kernels: -3 % / +1.5 % (profiles/history/r02_ab_extract_bpl.txt), experiments library only
             rc = tune.two_blocks ? launch_extract<svs::QM_POW2, 2>(rows, total, st, d_gray, g, qp, d_bits_packed_out, bytes)
                                  : launch_extract<svs::QM_POW2, 1>(rows, total, st, d_gray, g, qp, d_bits_packed_out, bytes);
 #else

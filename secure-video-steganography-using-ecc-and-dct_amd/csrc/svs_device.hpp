@@ -70,7 +70,7 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 // Frames are streamed exactly once: non-temporal loads/stores keep them from displacing each other
-// in L2 / Infinity Cache (measured on MI355X: embed +5 %, extract +11 %, profiles/r01_ab_variants.txt)
+// in L2 / Infinity Cache (measured on MI355X: embed +5 %, extract +11 %, profiles/history/r01_ab_variants.txt)
 #if !defined(SVS_NO_NONTEMPORAL)
 #define SVS_LD(p) __builtin_nontemporal_load(p)
 #define SVS_ST(v, p) __builtin_nontemporal_store(v, p)
@@ -100,7 +100,7 @@ template <int BPL>
 __device__ __forceinline__ void store_rows(uint8_t *dst, int64_t row_pitch, const typename RowVec<BPL>::type (&v)[8]) {
 #if !defined(SVS_NO_STORE_SC1)
     // write-through (sc1) stores: the line is not kept in the XCD's L2 (measured against non-temporal stores,
-    // profiles/r01_ab_quant_exact.txt: one-shot copy 6.74 vs 6.55 TB/s; embed +1.5 % at n = 3, +9.5 % at n = 10).  The data registers must not be reused before
+    // profiles/history/r01_ab_quant_exact.txt: one-shot copy 6.74 vs 6.55 TB/s; embed +1.5 % at n = 3, +9.5 % at n = 10).  The data registers must not be reused before
     // the store has read them: s_nop 1 inside the string (cdna_hip_programming.md section 5.7 item 1).
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
@@ -302,7 +302,7 @@ __global__ __launch_bounds__(SVS_WG) void extract_kernel(const uint8_t *__restri
 // ---------------------------------------------------------------------------------------
 // Layout experiment (SVS_EXTRACT_SHUFFLE=1, one coefficient row, FAST arithmetic): the north-star's sketch taken
 // literally - tiles staged in LDS, 8 lanes per block (one pixel row each), the vertical pass as cross-lane (DPP)
-// butterflies, one coefficient per lane.  Kept for the A/B in profiles/r01_ab_layout.txt; the shipped kernels keep a
+// butterflies, one coefficient per lane.  Kept for the A/B in profiles/history/r01_ab_layout.txt; the shipped kernels keep a
 // whole block in one lane.
 // ---------------------------------------------------------------------------------------
 __device__ __forceinline__ float dpp_add(float x, int ctrl_is) {  // x + x from the partner lane
@@ -752,6 +752,11 @@ __device__ __forceinline__ uint32_t guard_phase2_wg(GuardEntry *entries, float *
 #endif
 template <int U>
 constexpr int kEmbedMinWaves = U == 2 ? SVS_U2_MIN_WAVES : 1;
+template <int BPL>
+__device__ __forceinline__ uint32_t row2_shadow(uint32_t gblock, const Geometry &g, bool &live) {
+    live = gblock < g.total_blocks;
+    return live ? gblock : g.total_blocks - (uint32_t)BPL;   // the host launches with total_blocks >= BPL (a multiple of BPL)
+}
 // two rows, one block per lane: original rows parked in LDS and phase 1 in place (guard_phase2_slots: 68 instead of 103
 // VGPRs, 5 instead of 4 waves per SIMD, 29.7 KB of LDS per workgroup).  The kernel is bound by vector issue either way, and
 // which form the compiler schedules better depends on the quantiser: general delta (QM_F32, the GUI's default 20) 2.62 vs
@@ -793,25 +798,26 @@ __global__ __launch_bounds__(SVS_WG, kEmbedMinWaves<U>) void embed_kernel(const 
     // (Round 5 tried block-row aligned tiles - a workgroup reads and writes ONE contiguous stretch, eight full pixel rows, at
     // the price of idle lanes - to bring the launch from the rate of a copy with this access pattern to that of a linear copy:
     // 1.73 vs 1.64 ms per 600 x 4K at n = 3, 3.15 vs 2.63 at n = 10, slower on every placement: profiles/r05_ab_row_tiles.txt.)
-    const uint32_t gblock = (tile_id(g.xcd_chunk) * (uint32_t)SVS_WG + threadIdx.x) * BPL;
+    // lanes past the end of the batch shadow its last block(s) - they load and compute like everybody else and never store - so
+    // that the row registers are defined on one path only (round 6: no zero-initialised copies at the joins)
+    bool live;
+    const uint32_t gblock = row2_shadow<BPL>((tile_id(g.xcd_chunk) * (uint32_t)SVS_WG + threadIdx.x) * BPL, g, live);
     const uint32_t n = g.n_ac;
     bool und_a = false, und_b = false, write = false;
     // n <= 15: the payload window of a block is its first word - kept in a register from phase 1, because re-reading it for
-    // the worklist is a global load in the life of every wave that replays (one-row kernel: 1.58 instead of 1.73 ms per
-    // 600 x 4K, and 93 instead of 100 VGPRs)
+    // the worklist is a global load in the life of every wave that replays
     constexpr bool KEPT = SVS_KEEP_WINDOW;
     uint32_t hi_a = 0, hi_b = 0, nb_a = 0;
     typename RowVec<BPL>::type v[8];
     uint32_t ax[8], ay[8], bx[8], by[8];
-    int64_t off = 0;
-    if (gblock < g.total_blocks) {
-        off = block_offset(gblock, g);
-        load_rows<BPL>(gray + off, g.row_pitch, v);
+    const int64_t off = block_offset(gblock, g);
+    load_rows<BPL>(gray + off, g.row_pitch, v);
 #pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            ax[r] = v[r].x; ay[r] = v[r].y;
-            if constexpr (BPL == 2) { bx[r] = v[r].z; by[r] = v[r].w; }
-        }
+    for (int r = 0; r < 8; ++r) {
+        ax[r] = v[r].x; ay[r] = v[r].y;
+        if constexpr (BPL == 2) { bx[r] = v[r].z; by[r] = v[r].w; }
+    }
+    if (live) {
         const uint64_t first = (uint64_t)gblock * n;  // stream index of this lane's first bit
         write = stego != gray;                         // past the budget: byte-identical copy (the reference's loops `break`, :130,:132)
         if (first < n_bits) {
@@ -1324,7 +1330,7 @@ __device__ __forceinline__ WaveUnits wave_units(uint32_t lane, uint32_t wave_fir
 // Cooperative load of the wave's BGR rows (SVS_BGR_DIRECT_LOAD disables it): every load instruction covers 512
 // contiguous bytes; the rows pass through a wave-private, double-buffered LDS row (2 x 192 units) from which each lane
 // picks its own 24 bytes and converts them to gray.  +6 % in extract_bgr_kernel over lanes loading their own rows at a
-// 24-byte stride (profiles/r01_aux_kernel_rates.txt).
+// 24-byte stride (profiles/history/r01_aux_kernel_rates.txt).
 __device__ __forceinline__ void wave_load_gray(const uint8_t *__restrict__ bgr, const Geometry &g, const ColourParams &c,
                                                const WaveUnits &wu, uint32_t wave_first, uint32_t lane, u32x2 *rowbuf,
                                                uint32_t (&ax)[8], uint32_t (&ay)[8]) {
@@ -1471,7 +1477,7 @@ __global__ __launch_bounds__(SVS_WG) void embed_bgr_kernel(const uint8_t *bgr_in
     const bool live = gblock < g.total_blocks;
     uint32_t ax[8], ay[8];
     // cooperative load, four rows at a time: +5..7 % over per-lane loads at a 24-byte stride with the streaming arithmetic (62 -> 78 VGPRs),
-    // neutral in EXACT mode; all eight rows at once cost 100+ VGPRs and gained 1 % (profiles/r01_aux_kernel_rates.txt)
+    // neutral in EXACT mode; all eight rows at once cost 100+ VGPRs and gained 1 % (profiles/history/r01_aux_kernel_rates.txt)
     wave_load_gray_halves(bgr_in, g, c, gblock - lane, lane, &lds_tile[wave][0][0], ax, ay);
     bool und = false;
     constexpr bool KEPT = !EXACT && U <= 2 && SVS_KEEP_WINDOW;   // see embed_kernel

@@ -2,7 +2,7 @@
 """Embed / extract kernel times against the number of coefficients per block: the default (guarded) mode - streaming kernels
 with the rigorous guard up to n = 15, the lane-per-block pocketfft kernel above - next to the exact mode, and the two extract
 families.  200 x 4K device-resident frames, delta 8 and 20.  (Round 3's version compared a contract-level FAST arithmetic for
-n >= 16 with the exact kernel; that arithmetic is gone, profiles/r03_many_coefficients.txt keeps its numbers.)"""
+n >= 16 with the exact kernel; that arithmetic is gone, profiles/history/r03_many_coefficients.txt keeps its numbers.)"""
 import ctypes as C, os, statistics, sys
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(REPO, "secure-video-steganography-using-ecc-and-dct_amd"))

@@ -31,7 +31,8 @@ out = {"workload": {"frames": F, "height": H, "width": W, "n_ac": n},
        "calibration": {"FETCH_SIZE_scale_from_frame_sse_kernel": fetch_scale,
                        "WRITE_SIZE_scale_from_fill_synthetic_kernel": write_scale}, "kernels": {}}
 extract_name = "extract_kernel" if ("extract_kernel", "FETCH_SIZE") in mean else "extract_exact_kernel"   # n <= 7 uses the exact one
-kerns = [("embed_kernel", 2 * px + px * n // 512), (extract_name, px + px * n // 512)]
+embed_name = "embed_row1_kernel" if ("embed_row1_kernel", "FETCH_SIZE") in mean else "embed_kernel"   # n <= 7: the integer-domain one-row kernel (round 6)
+kerns = [(embed_name, 2 * px + px * n // 512), (extract_name, px + px * n // 512)]
 if ("embed_exact_kernel", "FETCH_SIZE") in mean:
     kerns.append(("embed_exact_kernel", 2 * px + px * n // 512))
 for kern, alg in kerns:
@@ -57,7 +58,7 @@ with open(os.path.join(repo, "profiles", f"{tag}_pmc_summary.json"), "w") as fh:
 if n == 3:
   with open(os.path.join(repo, "profiles", "hbm_traffic.json"), "w") as fh:
     json.dump({"frames": F, "height": H, "width": W, "n_ac": n,
-               "embed_bytes_per_launch": out["kernels"]["embed_kernel"]["hbm_bytes_per_launch"],
+               "embed_bytes_per_launch": out["kernels"][embed_name]["hbm_bytes_per_launch"],
                "captured": captured, "kernel_source_sha256": kernel_source_sha(),
                "extract_bytes_per_launch": out["kernels"][extract_name]["hbm_bytes_per_launch"],
                "source": f"profiles/{tag}_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, tools/gpu_pmc.sh)"},
