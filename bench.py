@@ -59,6 +59,10 @@ def parse_args(argv=None):
     ap.add_argument("--rehearse-gloo", action="store_true",
                     help="rank-logic rehearsal on a box with fewer GPUs than ranks: gloo backend, ranks share "
                          "GPUs, collectives staged through host memory (numbers are NOT bench results)")
+    ap.add_argument("--pmc-check", action="store_true",
+                    help="measure roofline.traffic in THIS run instead of reading the committed capture: before this process touches "
+                         "the GPU, two child processes run 2 steps of the same workload under `rocprofv3 --pmc FETCH_SIZE` / "
+                         "`--pmc WRITE_SIZE` (+ --kernel-trace only); N = 1, needs rocprofv3 on PATH")
     ap.add_argument("--inject-gather-swap", action="store_true",
                     help="TEST HOOK: rank 0 swaps the first two slices of the gathered stream before it checks them - the run must "
                          "then end with a non-zero exit code (tests/test_bench_gpu.py)")
@@ -203,6 +207,55 @@ def round_trip_verdict(parity_sample, bit_errors, delta, n_ac, gather_ok=None):
     return None
 
 
+def pmc_traffic_check(args):
+    """--pmc-check: HBM bytes per embed launch of this workload from two FRESH child processes (never a re-exec of a process
+    that has initialised the GPU; the program stands directly after `--`), one counter per pass as MI355X_MICROARCH.md
+    prescribes: FETCH_SIZE (KiB; on gfx950 half the bytes of a coalesced stream - the factor is calibrated in the same pass
+    on frame_sse_kernel's known 2 F H W bytes) and WRITE_SIZE (KiB; calibrated on fill_synthetic_kernel's F H W).
+    -> (bytes per embed launch, description) or (None, why not)"""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3")
+    if exe is None:
+        return None, "rocprofv3 is not on PATH"
+    px = args.frames * args.height * args.width
+    work = ["--steps", "2", "--warmup", "1", "--cpu-frames", "0", "--frames", str(args.frames), "--height", str(args.height),
+            "--width", str(args.width), "--n-ac", str(args.n_ac), "--delta", repr(args.delta)] + (["--mode", args.mode] if args.mode else [])
+    means = {}
+    tmp = tempfile.mkdtemp(prefix="svs_pmc_", dir=os.environ.get("TMPDIR", "/tmp"))
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, counter)
+            env = dict(os.environ, TMPDIR=os.environ.get("TMPDIR", "/tmp"))
+            res = subprocess.run([exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", out, "--",
+                                  sys.executable, os.path.abspath(__file__)] + work, env=env, capture_output=True, text=True, timeout=600)
+            if res.returncode != 0:
+                return None, f"rocprofv3 --pmc {counter} pass failed (exit {res.returncode})"
+            acc = {}
+            for path in glob.glob(os.path.join(out, "**", "*_counter_collection.csv"), recursive=True):
+                with open(path) as fh:
+                    for r in csv.DictReader(fh):
+                        if r["Counter_Name"] == counter:
+                            k = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("svs::", "").split("<")[0]
+                            acc.setdefault(k, []).append(float(r["Counter_Value"]))
+            means[counter] = {k: sum(v) / len(v) for k, v in acc.items()}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    fetch, write = means["FETCH_SIZE"], means["WRITE_SIZE"]
+    embed = next((k for k in ("embed_row1_kernel", "embed_kernel", "embed_exact_kernel") if k in fetch and k in write), None)
+    if embed is None or "frame_sse_kernel" not in fetch or "fill_synthetic_kernel" not in write:
+        return None, "the counter passes did not see the kernels they calibrate on"
+    fetch_scale = 2 * px / (fetch["frame_sse_kernel"] * 1024)          # 2.0 on gfx950 (guide: FETCH_SIZE counts half)
+    write_scale = px / (write["fill_synthetic_kernel"] * 1024)         # 1.0
+    traffic = fetch[embed] * 1024 * fetch_scale + write[embed] * 1024 * write_scale
+    return traffic, (f"measured in this run: two child passes `rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- python bench.py "
+                     f"--steps 2 ...` of this workload; {embed}; FETCH_SIZE x {fetch_scale:.4f} (calibrated on frame_sse_kernel), "
+                     f"WRITE_SIZE x {write_scale:.4f} (fill_synthetic_kernel)")
+
+
 def usable_cpus() -> int:
     """CPUs this process may actually use: scheduler affinity, further limited by a cgroup CPU quota if one is set
     (a GPU box hands each job a share of the host, not the 256 logical cores os.cpu_count() reports)."""
@@ -254,6 +307,9 @@ def main():
                              "(python bench.py, no --gpus / --force-dist) or launch the ranks with torch.distributed.run "
                              "under the profiler yourself")
         raise SystemExit(launch_ranks(args))             # parent of the ranks: never initialises the GPU
+    pmc_live = None
+    if args.pmc_check and int(os.environ.get("WORLD_SIZE", "1")) == 1 and "RANK" not in os.environ:
+        pmc_live = pmc_traffic_check(args)                   # child processes, before the first HIP call of this one
     cpu_parallel = None
     if args.cpu_frames > 0 and int(os.environ.get("WORLD_SIZE", "1")) == 1:
         cpu_parallel = cpu_baseline_all_cores(args)          # before the first HIP call of this process
@@ -471,6 +527,11 @@ def main():
                                              "reported as null; re-run tools/gpu_pmc.sh + tools/pmc_summary.py"}
             except Exception:
                 traffic, traffic_source = None, None
+        if pmc_live is not None:                 # --pmc-check: this run's own counter passes replace the committed capture
+            if pmc_live[0] is not None:
+                traffic, traffic_source = pmc_live[0], {"how": pmc_live[1]}
+            else:
+                traffic_source = dict(traffic_source or {}, pmc_check_failed=pmc_live[1])
         result = {
             "metric": "Mpixels/sec embed+extract round-trip at 4K; payload bit-error rate (must be 0)",
             "value": mpix_s, "unit": "Mpix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -85,6 +85,26 @@ def test_gather_exit_rule_at_delta_4_and_with_a_swapped_slice():
         assert "gathered bit stream" in res.stderr + res.stdout
 
 
+def test_pmc_check_measures_the_traffic_in_the_run():
+    """`--pmc-check` replaces the committed capture by two counter passes of this very run (fresh child
+    processes under rocprofv3, before the parent touches the GPU): HBM bytes per embed launch = the algorithmic bytes"""
+    import shutil
+    if shutil.which("rocprofv3") is None:
+        pytest.skip("rocprofv3 is not on PATH")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", TMPDIR="/tmp")
+    env.pop("RANK", None)
+    env.pop("WORLD_SIZE", None)
+    res = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--pmc-check", "--steps", "3", "--warmup", "1", "--frames", "48",
+                          "--height", "1080", "--width", "1920", "--cpu-frames", "0"], env=env, capture_output=True, text=True, timeout=900,
+                         cwd="/tmp")
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    r = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][0])
+    roof = r["roofline"]
+    assert roof["traffic"] is not None, roof["traffic_source"]
+    assert "measured in this run" in roof["traffic_source"]["how"]
+    assert 0.97 < roof["traffic"] / roof["algorithmic_bytes_per_launch"] < 1.05, roof
+
+
 def test_refuses_to_start_ranks_under_a_profiler():
     env = dict(os.environ, ROCP_TOOL_LIBRARIES="/opt/rocm/lib/rocprofiler-sdk/librocprofiler-sdk-tool.so")
     env.pop("RANK", None)

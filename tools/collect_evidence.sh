@@ -1,5 +1,5 @@
 #!/bin/bash
-# Copy what tools/gpu/r5_evidence.sh (round 4: r4_evidence.sh) left under gpurun_out/ev into profiles/ (run in the build container, where .git is):
+# Copy what tools/gpu/r6_evidence.sh (rounds 4, 5: r4_evidence.sh, r5_evidence.sh - in git history) left under gpurun_out/ev into profiles/ (run in the build container, where .git is):
 #   tools/collect_evidence.sh r04_c      -> profiles/r04_c_bench.json, ..., and the un-suffixed counter / probe / A/B files
 # Every kernel-stats file is headed by the commit and by the kernel-source hash bench.py computes.
 set -eu
@@ -29,6 +29,8 @@ if [ -f $E/tie_fallback_new.txt ]; then
   { echo "== this build ($REV)"; grep -v amdgpu.ids $E/tie_fallback_new.txt; echo; echo "== round-2 library (lib/variants/libsvsdct_r02.so, rebuilt from 68f741a), same box"; grep -v amdgpu.ids $E/tie_fallback_r02.txt; } > profiles/${ROUND}_tie_fallback_rate.txt
 fi
 [ -f $E/ab_vs_r02.txt ] && { echo "# commit $REV"; cat $E/ab_vs_r02.txt; } > profiles/${ROUND}_ab_vs_r02.txt
+[ -f $E/ab_vs_earlier.txt ] && { echo "# commit $REV: tools/ab_bench.py, one process, 11 interleaved rounds, single launches between synchronisations; lib/variants/libsvsdct_r05.so and _r02.so rebuilt from git by make -C csrc r05 r02"; cat $E/ab_vs_earlier.txt; } > profiles/${ROUND}_ab_vs_earlier.txt
+[ -f $E/placements.txt ] && { echo "# commit $REV: tools/placement_ab.py --pairs 6 --rounds 3 (sustained bursts of 8 launches; this = the product library, r05 / r02 = the libraries of those rounds rebuilt from git, this_copy = this build's launch with an empty payload: its access pattern with the arithmetic skipped, copy = 16 bytes per lane, linear)"; grep -v amdgpu.ids $E/placements.txt; } > profiles/${ROUND}_placements.txt
 [ -f $E/ab_n15_n16.txt ] && { echo "# commit $REV: tools/ab_bench.py, 600 x 4K, single launches between synchronisations, 7 interleaved rounds - the two-row streaming kernel at its last n against the lane-per-block pocketfft kernel at the first n it has to take"; cat $E/ab_n15_n16.txt; } > profiles/${ROUND}_ab_n15_n16.txt
 for i in 2 3; do [ -s $E/bench_process_$i.json ] && cp $E/bench_process_$i.json profiles/${TAG}_bench_process_$i.json; done
 [ -f $E/parity_report.json ] && cp $E/parity_report.json profiles/${ROUND}_parity_report.json

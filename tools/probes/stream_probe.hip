@@ -65,10 +65,18 @@ void go(const Cfg &c, const uint8_t *s, uint8_t *d) {
 
 int main(int argc, char **argv) {
     const int pairs = argc > 1 ? atoi(argv[1]) : 4, burst = 7;
+    const int kind = argc > 2 ? atoi(argv[2]) : 0;   // 0 hipMalloc, 1 fine-grained, 2 uncached, 3 physically contiguous
+    const bool brief = argc > 3;
     std::vector<std::pair<uint8_t *, uint8_t *>> bufs;
+    auto alloc = [&](uint8_t **p) {
+        if (kind == 0) { CK(hipMalloc(p, BYTES)); return; }
+        const unsigned flags = kind == 1 ? hipDeviceMallocFinegrained : kind == 2 ? hipDeviceMallocUncached : hipDeviceMallocContiguous;
+        CK(hipExtMallocWithFlags((void **)p, BYTES, flags));
+    };
+    printf("# allocation kind %d (0 hipMalloc, 1 fine-grained, 2 uncached, 3 contiguous)\n", kind);
     for (int k = 0; k < pairs; ++k) {
         uint8_t *a, *b;
-        CK(hipMalloc(&a, BYTES)); CK(hipMalloc(&b, BYTES));
+        alloc(&a); alloc(&b);
         CK(hipMemset(a, 17 + k, BYTES));
         bufs.push_back({a, b});
     }
@@ -82,6 +90,7 @@ int main(int argc, char **argv) {
     for (auto &e : ev) CK(hipEventCreate(&e));
     printf("# median ms per copy of %.3f GB (read) + the same written; %d placements\n", BYTES / 1e9, pairs);
     for (const Cfg &c : cfgs) {
+        if (brief && !(c.R == 8 && c.order == 0 && c.map == 1 && c.cap == 4) && !(c.R == 1 && c.cap == 0)) continue;
         printf("%-24s", c.name);
         for (auto &p : bufs) {
             CK(hipEventRecord(ev[0]));
