@@ -906,91 +906,6 @@ SVS_HD void embed_block_exact(uint32_t (&rx)[8], uint32_t (&ry)[8], uint32_t n, 
 #define SVS_GUARD_DELTA_MIN 0.25
 #define SVS_GUARD_DELTA_MAX 4096.0
 
-// one coefficient row (n <= 7), in two steps.
-// guard_decide: the floor of the change of each of the 8 pixel columns (the same in all 8 rows: only row 0 of the coefficient
-// matrix is touched) and whether the block is undecided; the pixels are not modified.
-template <int QM>
-SVS_HD bool guard_decide(const uint32_t (&rx)[8], const uint32_t (&ry)[8], uint32_t n, uint32_t nb, uint32_t hi, uint32_t lo,
-                         const QimParams &qp, float (&fl)[8]) {
-    // vertical pass, row 0 only: pocketfft's X[0] of a column of integers is fl(colsum * sqrt(2)/4) - its sums are exact
-    // integers and the one product rounds once - which is what the packed 16-bit column sums give (SVS_A0 is that float)
-    float V[8];
-    uint32_t S = 0, Q = 0;
-#pragma unroll
-    for (int half = 0; half < 2; ++half) {
-        uint32_t te = 0, to = 0;   // columns (0, 2) and (1, 3) of this half as 16-bit lanes, each <= 2040
-#pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            const uint32_t w = half ? ry[r] : rx[r];
-            te += w & 0x00ff00ffu;
-            to += (w >> 8) & 0x00ff00ffu;
-            Q = dot4_u8(w, w, Q);
-        }
-        V[4 * half + 0] = (float)(te & 0xffffu) * SVS_A0;
-        V[4 * half + 1] = (float)(to & 0xffffu) * SVS_A0;
-        V[4 * half + 2] = (float)(te >> 16) * SVS_A0;
-        V[4 * half + 3] = (float)(to >> 16) * SVS_A0;
-        const uint32_t t = te + to;
-        S += (t & 0xffffu) + (t >> 16);
-    }
-    float D[8];
-    pf::dct2_8(V, D);   // row 0 of the coefficient matrix, bit-identical to scipy's
-#pragma unroll
-    for (int k = 1; k < 8; ++k) {
-        float change = 0.0f;
-        if ((uint32_t)k <= n) {  // wave-uniform
-            const int i = k - 1;
-            const int bit = (int)window_bit(hi, lo, i);
-            const float c = D[k];
-            int q = quant_index<QM>(c, qp);
-            q = force_parity(q, bit);
-            float cn;
-            if constexpr (QM == QM_DOUBLE) cn = (float)((double)q * qp.delta_d);
-            else cn = (float)q * qp.delta_f;
-            change = ((uint32_t)i < nb) ? cn - c : 0.0f;
-        }
-        D[k] = change;
-    }
-    D[0] = 0.0f;
-    float P[8];
-    idct8<8, true>(D, P);
-    // BETA for this block: 64 Q - S^2 = 64 * (sum of squared deviations from the mean), an exact integer < 2^32
-    const float spread = guard_sqrt((float)(64u * Q - S * S));
-    const float beta = fmaf(qp.g_sum, (float)S, fmaf(qp.g_resid, spread, qp.g_delta));
-    float worst = 0.0f;   // largest |frac(change) - 1/2| among the 8 columns
-#pragma unroll
-    for (int x = 0; x < 8; ++x) {
-        const float ch = P[x] * SVS_A0;
-        fl[x] = floorf(ch);
-        worst = fmaxf(worst, fabsf((ch - fl[x]) - 0.5f));
-    }
-    return nb > 0 && !(worst < 0.5f - beta);   // nb == 0: the reference never enters the block (:130,:132)
-}
-
-// the cheap result: pixel + floor(change of its column), saturated (trunc(clip(x + c)) == clip(x + floor(c)) for integer x, :171).
-// (Round 4 tried the add in the integer domain - column deltas packed once per block, v_pk_add_i16 + v_sat_pk_u8_i16 + v_perm_b32
-// per row dword: 128 instead of 192 instructions per block, same bytes - and measured it 6 % SLOWER in sustained bursts
-// (1.63-1.66 vs 1.54 ms per 600 x 4K, profiles/r04_ab_one_row_store.txt): this kernel is bound by HBM, not by vector issue.)
-SVS_HD void guard_apply(uint32_t (&rx)[8], uint32_t (&ry)[8], const float (&fl)[8]) {
-#define SVS_OUTCOL(X, W, B)                                                           \
-    _Pragma("unroll") for (int y = 0; y < 8; ++y) W[y] = put_pixel<B>(ubyte_to_float<B>(W[y]) + fl[X], W[y]);
-    SVS_OUTCOL(0, rx, 0) SVS_OUTCOL(1, rx, 1) SVS_OUTCOL(2, rx, 2) SVS_OUTCOL(3, rx, 3)
-    SVS_OUTCOL(4, ry, 0) SVS_OUTCOL(5, ry, 1) SVS_OUTCOL(6, ry, 2) SVS_OUTCOL(7, ry, 3)
-#undef SVS_OUTCOL
-}
-
-// decide, then apply, in the float domain: on return rx/ry hold the block's stego pixels - or, when the result is true
-// (undecided), its original pixels, untouched.  The saturating form: what embed_block_guarded falls back to for a block in
-// which a pixel could clip at 0 / 255.
-template <int QM>
-SVS_HD bool embed_block_guarded_float(uint32_t (&rx)[8], uint32_t (&ry)[8], uint32_t n, uint32_t nb, uint32_t hi, uint32_t lo,
-                                      const QimParams &qp) {
-    float fl[8];
-    const bool undecided = guard_decide<QM>(rx, ry, n, nb, hi, lo, qp, fl);
-    if (!undecided) guard_apply(rx, ry, fl);
-    return undecided;
-}
-
 // One coefficient through the quantiser, in the float domain: change = fl(q' delta) - c with q' = round-half-even(c / delta)
 // forced to the parity of `bit` (config_and_setup.py:148-156).  t + 1.5 * 2^23 rounds t to the nearest-even integer q AND leaves
 // q in the low mantissa bits of the sum (|t| < 2^22: delta >= 1/4 and |c| <= 2040 here), so the parity is forced on the bit
@@ -1021,7 +936,8 @@ SVS_HD float qim_change(float c, uint32_t bit, const QimParams &qp) {
     }
 }
 
-// ---- one coefficient row in the INTEGER domain (round 6) --------------------------------------------------------------
+// ---- one coefficient row (n <= 7) in the INTEGER domain (round 6; rounds 3-5 applied the same eight floors in the float domain:
+// byte -> float, add, saturating float -> byte for each of the 64 pixels) ------------------------------------------------
 // With n <= 7 the change is the same in all 8 rows of a pixel column, so the block's result is pixel + d[x] with eight
 // integers d[x] = floor(change of column x).  When no pixel of the block can leave [0, 255] - min pixel + min d >= 0 and
 // max pixel + max d <= 255 - the saturation of the store never acts, and because  sum_j (p_j + d_j) 256^j = P + D  with
@@ -1068,12 +984,6 @@ SVS_HD int imax3(int a, int b, int c) { const int m = a > b ? a : b; return m > 
 #else
 #define SVS_PIN3(a, b, c) ((void)0)
 #endif
-#ifndef SVS_ROW1_FENCE_EVERY
-#define SVS_ROW1_FENCE_EVERY 2
-#endif
-#ifndef SVS_ROW1_FENCE
-#define SVS_ROW1_FENCE() SVS_SCHED_FENCE()
-#endif
 #define SVS_ROW1_UNDECIDED 1u   // guard_decide_int: BETA does not separate some column's change from the integer grid
 #define SVS_ROW1_MAY_CLIP 2u    //                   min pixel + min d < 0 or max pixel + max d > 255: the plain add must not be used
 
@@ -1114,14 +1024,13 @@ SVS_HD uint32_t pk_clamp_u8_i16(uint32_t a) {   // lane-wise clamp of signed 16-
 #endif
 }
 
-// NFIX (1..7, or 0 = run-time n): the coefficient count at compile time - transform outputs nobody reads and inverse inputs
-// that are known zeros disappear from the code (values unchanged: x + 0 and fma(0, c, x) are exact).
 // -> SVS_ROW1_* flags and the column deltas (meaningful unless SVS_ROW1_UNDECIDED).
-template <int QM, int NFIX = 0>
-SVS_HD uint32_t guard_decide_int(const uint32_t (&rx)[8], const uint32_t (&ry)[8], uint32_t n_rt, uint32_t nb, uint32_t hi,
+// (A compile-time coefficient count - n = 3, BASELINE configs[2] - removes a quarter of the instructions and changes nothing
+// measurable: the kernel's arithmetic is hidden behind its memory traffic, 1.6144 vs 1.6056 ms per 600 x 4K in a same-process
+// A/B.  Not instantiated.)
+template <int QM>
+SVS_HD uint32_t guard_decide_int(const uint32_t (&rx)[8], const uint32_t (&ry)[8], uint32_t n, uint32_t nb, uint32_t hi,
                                  const QimParams &qp, ColumnDeltas &cd) {
-    static_assert(NFIX >= 0 && NFIX <= 7, "one coefficient row");
-    const uint32_t n = NFIX ? (uint32_t)NFIX : n_rt;
     float V[8];
     uint32_t S = 0, Q = 0, mn = 0x00ff00ffu, mx = 0u;
 #pragma unroll
@@ -1136,7 +1045,7 @@ SVS_HD uint32_t guard_decide_int(const uint32_t (&rx)[8], const uint32_t (&ry)[8
             Q = dot4_u8(w, w, Q);
             mn = pk_min_u16(pk_min_u16(mn, e), o);
             mx = pk_max_u16(pk_max_u16(mx, e), o);
-            if ((r & (SVS_ROW1_FENCE_EVERY - 1)) == SVS_ROW1_FENCE_EVERY - 1) SVS_PIN3(mn, mx, Q);
+            if (r & 1) SVS_PIN3(mn, mx, Q);
         }
         V[4 * half + 0] = (float)(te & 0xffffu) * SVS_A0;
         V[4 * half + 1] = (float)(to & 0xffffu) * SVS_A0;
@@ -1144,15 +1053,15 @@ SVS_HD uint32_t guard_decide_int(const uint32_t (&rx)[8], const uint32_t (&ry)[8
         V[4 * half + 3] = (float)(to >> 16) * SVS_A0;
         const uint32_t t = te + to;
         S += (t & 0xffffu) + (t >> 16);
-        SVS_ROW1_FENCE();
+        SVS_SCHED_FENCE();
     }
     float D[8];
     pf::dct2_8(V, D);   // row 0 of the coefficient matrix, bit-identical to scipy's
-    SVS_ROW1_FENCE();
+    SVS_SCHED_FENCE();
 #pragma unroll
     for (int k = 1; k < 8; ++k) {
         float change = 0.0f;
-        if ((NFIX == 0 || k <= NFIX) && (uint32_t)k <= n)  // wave-uniform; the budget is applied below, for the one block it concerns
+        if ((uint32_t)k <= n)  // wave-uniform; the budget is applied below, for the one block it concerns
             change = qim_change<QM>(D[k], (hi >> (32 - k)) & 1u, qp);
         D[k] = change;
     }
@@ -1163,7 +1072,7 @@ SVS_HD uint32_t guard_decide_int(const uint32_t (&rx)[8], const uint32_t (&ry)[8
     }
     D[0] = 0.0f;
     float P[8];
-    idct8<NFIX ? NFIX + 1 : 8, true>(D, P);
+    idct8<8, true>(D, P);
     // BETA for this block: 64 Q - S^2 = 64 * (sum of squared deviations from the mean), an exact integer < 2^32
     const float spread = guard_sqrt((float)(64u * Q - S * S));
     const float beta = fmaf(qp.g_sum, (float)S, fmaf(qp.g_resid, spread, qp.g_delta));
@@ -1216,12 +1125,12 @@ SVS_HD void apply_deltas_clipped(uint32_t (&rx)[8], uint32_t (&ry)[8], const Col
 // decide, then apply: on return rx/ry hold the block's stego pixels - or, when the result is true (undecided), its original
 // pixels, untouched (the host emulation, the one-block-per-lane and fused-colour kernels; embed_row1_kernel chooses the
 // store form per WAVE instead of per lane)
-template <int QM, int NFIX = 0>
+template <int QM>
 SVS_HD bool embed_block_guarded(uint32_t (&rx)[8], uint32_t (&ry)[8], uint32_t n, uint32_t nb, uint32_t hi, uint32_t lo,
                                 const QimParams &qp) {
     (void)lo;   // one coefficient row: the window is its first word
     ColumnDeltas cd;
-    const uint32_t flags = guard_decide_int<QM, NFIX>(rx, ry, n, nb, hi, qp, cd);
+    const uint32_t flags = guard_decide_int<QM>(rx, ry, n, nb, hi, qp, cd);
     if (flags & SVS_ROW1_UNDECIDED) return true;
     if (flags & SVS_ROW1_MAY_CLIP) apply_deltas_clipped(rx, ry, cd);
     else apply_deltas_plain(rx, ry, cd);

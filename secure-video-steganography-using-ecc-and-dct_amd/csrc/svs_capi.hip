@@ -196,12 +196,8 @@ int launch_embed(int rows, uint64_t total, hipStream_t st, const uint8_t *gray, 
     }
     if (rows < 1 || rows > 2) return fail(SVS_ERR_INVALID_ARG, "internal: rows=%d, %d blocks per lane", rows, BPL);
     if (rows == 1) {   // one coefficient row: the integer-domain kernel (round 6; the round-5 kernel it replaced: commit a377b8d, experiments library, SVS_ROW1_OLD=1)
-        if (g.n_ac == 3 && knob("SVS_FIXED_N", 1) != 0)   // BASELINE configs[2]: "3 AC coeffs/block"
-            hipLaunchKernelGGL((svs::embed_row1_kernel<QM, BPL, 3>), grid, dim3(SVS_WG), lds_pad, st, gray, stego, g, qp, bits, bit_offset,
-                               n_bits, n_words SVS_COUNTER_ARG);
-        else
-            hipLaunchKernelGGL((svs::embed_row1_kernel<QM, BPL>), grid, dim3(SVS_WG), lds_pad, st, gray, stego, g, qp, bits, bit_offset,
-                               n_bits, n_words SVS_COUNTER_ARG);
+        hipLaunchKernelGGL((svs::embed_row1_kernel<QM, BPL>), grid, dim3(SVS_WG), lds_pad, st, gray, stego, g, qp, bits, bit_offset, n_bits,
+                           n_words SVS_COUNTER_ARG);
         SVS_HIP(hipGetLastError());
         return SVS_OK;
     }

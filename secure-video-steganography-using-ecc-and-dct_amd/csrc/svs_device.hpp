@@ -886,12 +886,6 @@ __global__ __launch_bounds__(SVS_WG, kEmbedMinWaves<U>) void embed_kernel(const 
 //   * the worklist deposit / collection moves rows as the 8-byte pairs they are held in.
 // Phases 2 and 3 as in embed_kernel.  gray and stego may alias.
 // ---------------------------------------------------------------------------------------
-#ifndef SVS_ROW1_CLIP_PATH
-#define SVS_ROW1_CLIP_PATH 1
-#endif
-#ifndef SVS_ROW1_MIN_WAVES
-#define SVS_ROW1_MIN_WAVES 1
-#endif
 // Rows stay in the load / store vectors: block A = components x, y of v[r], block B (two blocks per lane) = z, w.
 template <int BPL>
 __device__ __forceinline__ void row1_block(const typename RowVec<BPL>::type (&v)[8], int which, uint32_t (&rx)[8], uint32_t (&ry)[8]) {
@@ -985,11 +979,11 @@ __device__ __forceinline__ uint32_t row1_shadow(uint32_t gblock, const Geometry 
 
 // phases 1-3 for the rows `v` of global block(s) gb (already loaded from gray + off): decide / apply, exact replay of the
 // wave's undecided blocks, store.
-template <int QM, int BPL, int NFIX>
+template <int QM, int BPL>
 __device__ __forceinline__ uint32_t row1_process(typename RowVec<BPL>::type (&v)[8], uint32_t gb, bool live, int64_t off, uint64_t q,
                                                  const Geometry &g, const QimParams &qp, const Row1Args &a, GuardEntry *entries,
                                                  float *tile, uint32_t lane) {
-    const uint32_t n = NFIX ? (uint32_t)NFIX : g.n_ac;
+    const uint32_t n = g.n_ac;
     const uint64_t first = (uint64_t)gb * n;   // stream index of this lane's first bit
     bool und_a = false, und_b = false, clip = false;
     uint32_t hi_a = 0, hi_b = 0;
@@ -1001,7 +995,7 @@ __device__ __forceinline__ uint32_t row1_process(typename RowVec<BPL>::type (&v)
         {
             uint32_t rx[8], ry[8];
             row1_block<BPL>(v, 0, rx, ry);
-            flags = guard_decide_int<QM, NFIX>(rx, ry, n, block_budget(first, a.n_bits, n), hi_a, qp, ca);
+            flags = guard_decide_int<QM>(rx, ry, n, block_budget(first, a.n_bits, n), hi_a, qp, ca);
             und_a = (flags & SVS_ROW1_UNDECIDED) != 0;
             if (und_a) { ca.e_lo = 0u; ca.o_lo = 0u; ca.e_hi = 0u; ca.o_hi = 0u; }   // keeps its original pixels for the replay
         }
@@ -1012,7 +1006,7 @@ __device__ __forceinline__ uint32_t row1_process(typename RowVec<BPL>::type (&v)
             uint32_t rx[8], ry[8];
             row1_block<BPL>(v, 1, rx, ry);
             // a budget of 0 (only the lane the payload ends in can see it) leaves block B as it is: all its deltas are 0
-            flags = guard_decide_int<QM, NFIX>(rx, ry, n, block_budget(first + n, a.n_bits, n), hi_b, qp, cb);
+            flags = guard_decide_int<QM>(rx, ry, n, block_budget(first + n, a.n_bits, n), hi_b, qp, cb);
             und_b = (flags & SVS_ROW1_UNDECIDED) != 0;
             if (und_b) { cb.e_lo = 0u; cb.o_lo = 0u; cb.e_hi = 0u; cb.o_hi = 0u; }
             clip = clip || flags == SVS_ROW1_MAY_CLIP;
@@ -1021,7 +1015,7 @@ __device__ __forceinline__ uint32_t row1_process(typename RowVec<BPL>::type (&v)
     SVS_SCHED_FENCE();
     // The stores (every lane: the deltas of a lane without payload are 0).  Wave-uniform: when some block of the wave could
     // clip at 0 / 255, all of them take the saturating form - same bytes where nothing clips.
-    const bool clip_wave = SVS_ROW1_CLIP_PATH && __ballot(clip) != 0;
+    const bool clip_wave = __ballot(clip) != 0;
     {
         const uint32_t keep = clip_wave ? 0u : 0xffffffffu;
         const uint32_t a0 = packed_addend(ca.e_lo, ca.o_lo) & keep, a1 = packed_addend(ca.e_hi, ca.o_hi) & keep;
@@ -1050,8 +1044,8 @@ __device__ __forceinline__ uint32_t row1_process(typename RowVec<BPL>::type (&v)
     return redone;
 }
 
-template <int QM, int BPL, int NFIX = 0>
-__global__ __launch_bounds__(SVS_WG, SVS_ROW1_MIN_WAVES) void embed_row1_kernel(const uint8_t *gray, uint8_t *stego, const Geometry g,
+template <int QM, int BPL>
+__global__ __launch_bounds__(SVS_WG) void embed_row1_kernel(const uint8_t *gray, uint8_t *stego, const Geometry g,
                                                           const QimParams qp, const uint32_t *__restrict__ bits,
                                                           const uint64_t bit_offset, const uint64_t n_bits,
                                                           const uint32_t n_words SVS_REPLAY_COUNTER_PARAM) {
@@ -1064,10 +1058,10 @@ __global__ __launch_bounds__(SVS_WG, SVS_ROW1_MIN_WAVES) void embed_row1_kernel(
     typename RowVec<BPL>::type v[8];
     load_rows<BPL>(gray + off, g.row_pitch, v);
     const Row1Args a{gray, stego, bits, bit_offset, n_bits, n_words};
-    const uint32_t n = NFIX ? (uint32_t)NFIX : g.n_ac;
+    const uint32_t n = g.n_ac;
     uint64_t q = 0;
     if (live && (uint64_t)gb * n < n_bits) q = payload_qword(bits, n_words, bit_offset + (uint64_t)gb * n);
-    const uint32_t redone = row1_process<QM, BPL, NFIX>(v, gb, live, off, q, g, qp, a, &entries[wave][0], &tiles[wave][0], lane);
+    const uint32_t redone = row1_process<QM, BPL>(v, gb, live, off, q, g, qp, a, &entries[wave][0], &tiles[wave][0], lane);
 #if defined(SVS_EXPERIMENTS)
     if (replay_counter != nullptr && redone != 0 && lane == 0) atomicAdd(replay_counter, (unsigned long long)redone);
 #else
