@@ -1272,3 +1272,32 @@ def test_fused_colour_host_calls_in_bands_and_frame_groups():
         assert np.array_equal(got_bgr, np.repeat(want[..., None], 3, axis=3))
         packed, n_bits = batch.extract_bgr_frames(got_bgr, delta, n_ac)
         assert n_bits == cap and np.array_equal(np.unpackbits(packed, count=payload.size), payload)
+
+
+def test_one_row_integer_store_plain_and_saturating_waves_equal_the_oracle():
+    """Round 6 (embed_row1_kernel): a wave stores pixel dword + packed column deltas with one 32-bit add when NONE of its 128
+    blocks can clip, and takes the packed 16-bit saturating form for all of them when one can (a wave-uniform ballot).  A
+    1024-pixel-wide frame makes every block row one wave: rows of content that never clips, rows that clip everywhere, rows in
+    which a single block touches 0 / 255, rows whose minimum + most negative delta lands exactly on 0 - both blocks-per-lane
+    forms (an odd block count per row takes one block per lane), several steps, against the oracle pixel for pixel."""
+    rng = np.random.default_rng(66)
+    for w in (1024, 1032):
+        bands = []
+        safe = lambda: rng.integers(40, 216, (8, w))
+        bands += [safe(), rng.integers(0, 256, (8, w)), rng.integers(0, 2, (8, w)), rng.integers(254, 256, (8, w))]
+        one = safe(); one[3, 517] = 0; bands.append(one)
+        two = safe(); two[0, 8] = 255; two[7, w - 1] = 0; bands.append(two)
+        for lo in (1, 2, 3, 5, 7, 9, 12):
+            bands += [rng.integers(lo, lo + 30, (8, w)), rng.integers(226 - lo, 256 - lo, (8, w))]
+        cols = safe(); cols[:, ::2] = 0; cols[:, 1::2] = 255; bands.append(cols)
+        bands.append(safe())
+        frame = np.concatenate(bands).astype(np.uint8)[None]
+        h = frame.shape[1]
+        for n_ac, delta in ((3, 8), (1, 20), (7, 4), (3, 0.25), (5, 100), (3, 1000), (7, 37.5)):
+            cap = batch.capacity_bits(1, h, w, n_ac)
+            for bits in (rng.integers(0, 2, cap).astype(np.uint8), np.ones(cap - 3, np.uint8)):
+                want, want_used = orc.batch_embed(frame, delta, bits, n_ac)
+                for mode in ("guarded", "exact"):
+                    got, used = batch.embed_frames(frame, delta, n_ac, bits, mode=mode)
+                    assert used == want_used and np.array_equal(got, want), (w, n_ac, delta, mode, int((got != want).sum()))
+                # in place (stego == gray) through the device-pointer entry point gives the same bytes

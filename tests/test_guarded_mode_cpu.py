@@ -239,3 +239,43 @@ def test_launched_two_row_instantiations_equal_the_generic_one():
                 _, ref, ref_used = orc.frame_embed(cover, delta, bits, n_ac)
                 assert ua == ref_used and np.array_equal(a[0], ref), (name, n_ac, delta, n_bits)
     assert ra[0] > 0
+
+
+@pytest.mark.parametrize("n_ac", [1, 3, 7])
+def test_integer_domain_store_and_its_saturating_form_equal_the_oracle(n_ac):
+    """Round 6: with one coefficient row a decided block is pixel dword + packed column deltas (ONE 32-bit add) when nothing
+    can clip, and a packed 16-bit saturating add when something can.  Content at and around both ends of the byte range - where
+    a wrong "nothing clips" verdict would let a byte wrap into its neighbour - against the oracle, pixel for pixel:
+    two-level noise at 0/1 and 254/255, levels 0..12 and 243..255, 0 / 255 columns and rows, one extreme pixel per block,
+    blocks whose minimum + most negative delta is exactly 0, full-range noise; steps from the guard's smallest to its largest."""
+    rng = np.random.default_rng(600 + n_ac)
+    h, w = 32, 64
+    yy, xx = np.mgrid[0:h, 0:w]
+
+    def classes():
+        yield "0/1 noise", rng.integers(0, 2, (h, w))
+        yield "254/255 noise", rng.integers(254, 256, (h, w))
+        yield "0..12", rng.integers(0, 13, (h, w))
+        yield "243..255", rng.integers(243, 256, (h, w))
+        yield "0/255 columns", np.where(xx % 2 == 0, 0, 255)
+        yield "0/255 rows", np.where(yy % 2 == 0, 0, 255)
+        yield "one extreme pixel per block", np.where((yy % 8 == 3) & (xx % 8 == 5), 0, np.where((yy % 8 == 0) & (xx % 8 == 0), 255, 128))
+        yield "full-range noise", rng.integers(0, 256, (h, w))
+        yield "mid noise with a 0 and a 255", np.where((yy % 8 == 0) & (xx % 8 == 0), 0, np.where((yy % 8 == 7) & (xx % 8 == 7), 255,
+                                                                                             rng.integers(100, 156, (h, w))))
+        for lo in (1, 2, 3, 5, 6, 7, 9, 12):          # the block minimum sits a few levels above 0: min + delta lands on, above and below 0
+            yield f"floor {lo}", rng.integers(lo, lo + 30, (h, w))
+            yield f"ceiling {255 - lo}", rng.integers(226 - lo, 256 - lo, (h, w))
+
+    cap = (h // 8) * (w // 8) * n_ac
+    checked = 0
+    for name, img in classes():
+        frame = np.asarray(img, np.uint8)
+        for delta in (0.25, 1, 3, 8, 20, 37.5, 100, 1000, 4096):
+            for bits in (rng.integers(0, 2, cap).astype(np.uint8), np.ones(cap, np.uint8), np.zeros(cap - 5, np.uint8)):
+                _, want, want_used = orc.frame_embed(frame, delta, bits, n_ac)
+                got, used = emu_embed(frame, delta, n_ac, bits, exact=4)
+                assert used == want_used, (name, delta)
+                assert np.array_equal(got[0], want), (name, n_ac, delta, int((got[0] != want).sum()))
+                checked += 1
+    assert checked == 25 * 9 * 3
