@@ -1300,4 +1300,3 @@ def test_one_row_integer_store_plain_and_saturating_waves_equal_the_oracle():
                 for mode in ("guarded", "exact"):
                     got, used = batch.embed_frames(frame, delta, n_ac, bits, mode=mode)
                     assert used == want_used and np.array_equal(got, want), (w, n_ac, delta, mode, int((got != want).sum()))
-                # in place (stego == gray) through the device-pointer entry point gives the same bytes
