@@ -23,14 +23,16 @@ __device__ __forceinline__ uint32_t tile_of(uint32_t map) {
     const uint32_t i = blockIdx.x;
     if (map == 0) return i;
     const uint32_t n = gridDim.x, q = n / 8u, r = n % 8u, x = i % 8u;
-    return (x < r ? x * (q + 1u) : r * (q + 1u) + (x - r) * q) + i / 8u;
+    const uint32_t base = x < r ? x * (q + 1u) : r * (q + 1u) + (x - r) * q, len = q + (x < r ? 1u : 0u);
+    const uint32_t stagger = map >> 4;     // every XCD starts x * stagger tiles into its eighth (and wraps)
+    return base + (i / 8u + x * stagger) % len;
 }
 
-template <int R, int ORDER>
-__global__ __launch_bounds__(256) void rows_kernel(const uint8_t *src, uint8_t *dst, uint32_t map, uint32_t lanes_total, uint32_t never) {
+template <int R, int ORDER, int WG = 256>
+__global__ __launch_bounds__(WG) void rows_kernel(const uint8_t *src, uint8_t *dst, uint32_t map, uint32_t lanes_total, uint32_t never) {
     extern __shared__ uint32_t pad[];
     if (never == 0x12345678u) pad[threadIdx.x] = 1;
-    const uint32_t L = tile_of(map) * 256u + threadIdx.x;
+    const uint32_t L = tile_of(map) * (uint32_t)WG + threadIdx.x;
     if (L >= lanes_total) return;
     const uint32_t grp = L / STRIPS, s = L - grp * STRIPS;
     const int64_t off = (int64_t)grp * R * PITCH + s * 16;
@@ -40,25 +42,43 @@ __global__ __launch_bounds__(256) void rows_kernel(const uint8_t *src, uint8_t *
         for (int r = 0; r < R; ++r) v[r] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(src + off + r * (int64_t)PITCH));
 #pragma unroll
         for (int r = 0; r < R; ++r) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(dst + off + r * (int64_t)PITCH), "v"(v[r]) : "memory");
-    } else {
+    } else if constexpr (ORDER == 1) {
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             v[r] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(src + off + r * (int64_t)PITCH));
             asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(dst + off + r * (int64_t)PITCH), "v"(v[r]) : "memory");
         }
+    } else if constexpr (ORDER == 2) {   // read only: the rows are folded into one dword that is (never) stored
+        u32x4 acc = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int r = 0; r < R; ++r) acc ^= __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(src + off + r * (int64_t)PITCH));
+        if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345679u && never == 1u) dst[off] = 1;
+    } else {                             // write only
+        const u32x4 c = {L, map, lanes_total, never};
+#pragma unroll
+        for (int r = 0; r < R; ++r) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(dst + off + r * (int64_t)PITCH), "v"(c) : "memory");
     }
 }
 
-struct Cfg { const char *name; int R, order, map, cap; };
+struct Cfg { const char *name; int R, order, map, cap, wg; };   // wg: threads per workgroup (0 = 256); cap counts workgroups per CU
 
-template <int R, int ORDER>
+template <int R, int ORDER, int WG = 256>
 void launch(const uint8_t *s, uint8_t *d, int map, int cap) {
     const uint32_t lanes = (uint32_t)(BYTES / (16ull * R));
     const uint32_t lds = cap ? ((160u * 1024u / cap) & ~255u) : 0u;
-    hipLaunchKernelGGL((rows_kernel<R, ORDER>), dim3((lanes + 255) / 256), dim3(256), lds, 0, s, d, (uint32_t)map, lanes, 0u);
+    hipLaunchKernelGGL((rows_kernel<R, ORDER, WG>), dim3((lanes + WG - 1) / WG), dim3(WG), lds, 0, s, d, (uint32_t)map, lanes, 0u);
 }
 void go(const Cfg &c, const uint8_t *s, uint8_t *d) {
-#define GO(RR) if (c.R == RR) { if (c.order) launch<RR, 1>(s, d, c.map, c.cap); else launch<RR, 0>(s, d, c.map, c.cap); }
+    if (c.wg && c.R == 8 && c.order == 0) {
+        switch (c.wg) {
+            case 64: launch<8, 0, 64>(s, d, c.map, c.cap); return;
+            case 128: launch<8, 0, 128>(s, d, c.map, c.cap); return;
+            case 512: launch<8, 0, 512>(s, d, c.map, c.cap); return;
+            case 1024: launch<8, 0, 1024>(s, d, c.map, c.cap); return;
+        }
+    }
+#define GO(RR) if (c.R == RR) { if (c.order == 1) launch<RR, 1>(s, d, c.map, c.cap); else if (c.order == 2) launch<RR, 2>(s, d, c.map, c.cap); \
+                      else if (c.order == 3) launch<RR, 3>(s, d, c.map, c.cap); else launch<RR, 0>(s, d, c.map, c.cap); }
     GO(1) GO(2) GO(4) GO(8) GO(16)
 #undef GO
 }
@@ -85,12 +105,20 @@ int main(int argc, char **argv) {
         {"R8 eighth", 8, 0, 1, 0}, {"R8 eighth cap4", 8, 0, 1, 4}, {"R8 eighth cap5", 8, 0, 1, 5}, {"R8 identity cap4", 8, 0, 0, 4},
         {"R8 eighth rowwise", 8, 1, 1, 0}, {"R8 eighth rowwise cap4", 8, 1, 1, 4}, {"R4 eighth cap4", 4, 0, 1, 4}, {"R4 eighth cap8", 4, 0, 1, 8},
         {"R2 eighth cap8", 2, 0, 1, 8}, {"R16 eighth cap4", 16, 0, 1, 4}, {"R16 eighth cap2", 16, 0, 1, 2}, {"R1 eighth cap4", 1, 0, 1, 4},
+        {"R1 identity READ", 1, 2, 0, 0}, {"R8 eighth cap4 READ", 8, 2, 1, 4}, {"R8 eighth READ", 8, 2, 1, 0},
+        {"R8 eighth wg64 cap16", 8, 0, 1, 16, 64}, {"R8 eighth wg128 cap8", 8, 0, 1, 8, 128}, {"R8 eighth wg512 cap2", 8, 0, 1, 2, 512},
+        {"R8 eighth wg1024 cap1", 8, 0, 1, 1, 1024}, {"R8 identity wg64 cap16", 8, 0, 0, 16, 64}, {"R8 eighth wg64 cap32", 8, 0, 1, 32, 64},
+        {"R8 e cap4 stagger 1", 8, 0, 1 | (1 << 4), 4}, {"R8 e cap4 stagger 8", 8, 0, 1 | (8 << 4), 4}, {"R8 e cap4 stagger 64", 8, 0, 1 | (64 << 4), 4},
+        {"R8 e cap4 stagger 512", 8, 0, 1 | (512 << 4), 4}, {"R8 e cap4 stagger 2373", 8, 0, 1 | (2373 << 4), 4}, {"R8 e cap4 stagger 1187", 8, 0, 1 | (1187 << 4), 4},
+        {"R8 e cap4 stagger 37", 8, 0, 1 | (37 << 4), 4}, {"R8 e cap4 stagger 4099", 8, 0, 1 | (4099 << 4), 4},
+        {"R1 identity WRITE", 1, 3, 0, 0}, {"R8 eighth cap4 WRITE", 8, 3, 1, 4}, {"R8 eighth WRITE", 8, 3, 1, 0}, {"R8 eighth cap2 WRITE", 8, 3, 1, 2},
     };
     hipEvent_t ev[16];
     for (auto &e : ev) CK(hipEventCreate(&e));
     printf("# median ms per copy of %.3f GB (read) + the same written; %d placements\n", BYTES / 1e9, pairs);
     for (const Cfg &c : cfgs) {
-        if (brief && !(c.R == 8 && c.order == 0 && c.map == 1 && c.cap == 4) && !(c.R == 1 && c.cap == 0)) continue;
+        if (brief && (c.wg != 0 || c.order >= 2)) continue;
+        if (brief && c.order < 2 && (c.map >> 4) == 0 && !(c.R == 8 && c.order == 0 && c.map == 1 && c.cap == 4) && !(c.R == 1 && c.cap == 0)) continue;
         printf("%-24s", c.name);
         for (auto &p : bufs) {
             CK(hipEventRecord(ev[0]));
