@@ -6,7 +6,7 @@
 #   bpl       two blocks per lane capped at 4 / 5 against one block per lane capped at 5 - 8, round-5 and round-2 libraries    -> r06_place_bpl.txt
 #   pitch     the access pattern (empty payload) at nine frame geometries, four placements, capped at 4 and uncapped           -> r06_pitch_probe_cap{4,0}.txt
 #   stream    tools/probes/stream_probe: pure copies, R rows per lane x cap, tile map, order                                   -> r06_stream_probe.txt
-#   split     tools/probes/stream_probe 5 0 brief: the R8 pattern's read and write streams apart, workgroup sizes, staggered XCD streams -> r06_stream_probe_split.txt
+#   split     tools/probes/stream_probe 5 0 (every configuration): the R8 pattern's read and write streams apart, workgroup sizes, staggered XCD streams -> r06_stream_probe_split.txt
 #             (and `stream_probe 4 <kind> brief` for kind = 0..3: allocation kinds -> r06_alloc_kinds.txt)
 #   caps      occupancy cap at n = 7 / general delta, odd block count per row, 1080p, n = 1; one block per lane                 -> r06_caps.txt
 # (the persistent, software-pipelined variant of the kernel - profiles/r06_stream_pipeline.txt - lived in the working tree between commits ac1b1d8 and a377b8d)
@@ -25,7 +25,7 @@ bpl)   python tools/placement_ab.py --pairs 6 --rounds 3 --cfg b2c4=exp:$C4 --cf
          --cfg b1c7=exp:SVS_EMBED_BPL=1,SVS_EMBED_WG_PER_CU=7 --cfg b1c8=exp:SVS_EMBED_BPL=1,SVS_EMBED_WG_PER_CU=8 --cfg r05=libsvsdct_r05.so --cfg r02=libsvsdct_r02.so > $E/bpl.txt 2>&1; grep -v amdgpu.ids $E/bpl.txt ;;
 pitch) for c in 4 0; do python tools/pitch_probe.py --pairs 4 --cap $c > $E/pitch_cap$c.txt 2>&1; grep -v amdgpu.ids $E/pitch_cap$c.txt; done ;;
 stream) tools/probes/stream_probe 4 > $E/stream_probe.txt 2>&1; cat $E/stream_probe.txt ;;
-split) tools/probes/stream_probe 5 0 brief > $E/stream_probe_split.txt 2>&1; cat $E/stream_probe_split.txt
+split) tools/probes/stream_probe 5 0 > $E/stream_probe_split.txt 2>&1; cat $E/stream_probe_split.txt
        for k in 0 1 2 3; do tools/probes/stream_probe 4 $k brief; done > $E/alloc_kinds.txt 2>&1 ;;
 caps)  : > $E/caps.txt
        for cfg in "--frames 600 --n-ac 7 --delta 20" "--frames 600 --n-ac 3 --w 3848" "--frames 2400 --h 1080 --w 1920 --n-ac 3" "--frames 300 --h 1080 --w 1920 --n-ac 3" "--frames 600 --n-ac 1 --delta 10"; do
