@@ -60,6 +60,29 @@ __global__ __launch_bounds__(WG) void rows_kernel(const uint8_t *src, uint8_t *d
     }
 }
 
+// A 32 KB tile of 8 rows x 4096 B per workgroup of 256 (pitch 4096: one workgroup = one group of rows), moved two ways:
+//   TRANSPOSED = 0  a lane moves 16 B of each of the 8 rows (the embed kernel's ownership: a wave's 8 accesses are 4096 B apart)
+//   TRANSPOSED = 1  wave w moves rows 2w and 2w + 1 whole: its 8 accesses are 8 consecutive KB (what a kernel that passes its
+//                   rows through an LDS transposition would issue) - the same bytes per workgroup, per wave and per instruction
+template <int TRANSPOSED>
+__global__ __launch_bounds__(256) void tile32k_kernel(const uint8_t *src, uint8_t *dst, uint32_t map, uint32_t tiles, uint32_t never) {
+    extern __shared__ uint32_t pad[];
+    if (never == 0x12345678u) pad[threadIdx.x] = 1;
+    const uint32_t tile = tile_of(map);
+    if (tile >= tiles) return;
+    const uint32_t w = threadIdx.x >> 6, l = threadIdx.x & 63u;
+    const int64_t base = (int64_t)tile * 32768;
+    u32x4 v[8];
+    int64_t off[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+        off[j] = TRANSPOSED ? base + (int64_t)(2 * w + j / 4) * 4096 + (64 * (j % 4) + l) * 16 : base + (int64_t)j * 4096 + threadIdx.x * 16;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(src + off[j]));
+#pragma unroll
+    for (int j = 0; j < 8; ++j) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(dst + off[j]), "v"(v[j]) : "memory");
+}
+
 struct Cfg { const char *name; int R, order, map, cap, wg; };   // wg: threads per workgroup (0 = 256); cap counts workgroups per CU
 
 template <int R, int ORDER, int WG = 256>
@@ -69,6 +92,13 @@ void launch(const uint8_t *s, uint8_t *d, int map, int cap) {
     hipLaunchKernelGGL((rows_kernel<R, ORDER, WG>), dim3((lanes + WG - 1) / WG), dim3(WG), lds, 0, s, d, (uint32_t)map, lanes, 0u);
 }
 void go(const Cfg &c, const uint8_t *s, uint8_t *d) {
+    if (c.order >= 10) {      // 32 KB tiles at pitch 4096: 10 = lane owns 8 rows, 11 = wave owns 2 whole rows
+        const uint32_t tiles = (uint32_t)(BYTES / 32768);
+        const uint32_t lds = c.cap ? ((160u * 1024u / c.cap) & ~255u) : 0u;
+        if (c.order == 10) hipLaunchKernelGGL((tile32k_kernel<0>), dim3(tiles), dim3(256), lds, 0, s, d, (uint32_t)c.map, tiles, 0u);
+        else hipLaunchKernelGGL((tile32k_kernel<1>), dim3(tiles), dim3(256), lds, 0, s, d, (uint32_t)c.map, tiles, 0u);
+        return;
+    }
     if (c.wg && c.R == 8 && c.order == 0) {
         switch (c.wg) {
             case 64: launch<8, 0, 64>(s, d, c.map, c.cap); return;
@@ -111,13 +141,15 @@ int main(int argc, char **argv) {
         {"R8 e cap4 stagger 1", 8, 0, 1 | (1 << 4), 4}, {"R8 e cap4 stagger 8", 8, 0, 1 | (8 << 4), 4}, {"R8 e cap4 stagger 64", 8, 0, 1 | (64 << 4), 4},
         {"R8 e cap4 stagger 512", 8, 0, 1 | (512 << 4), 4}, {"R8 e cap4 stagger 2373", 8, 0, 1 | (2373 << 4), 4}, {"R8 e cap4 stagger 1187", 8, 0, 1 | (1187 << 4), 4},
         {"R8 e cap4 stagger 37", 8, 0, 1 | (37 << 4), 4}, {"R8 e cap4 stagger 4099", 8, 0, 1 | (4099 << 4), 4},
+        {"T32K lane-rows cap4", 8, 10, 1, 4}, {"T32K wave-rows cap4", 8, 11, 1, 4}, {"T32K lane-rows", 8, 10, 1, 0}, {"T32K wave-rows", 8, 11, 1, 0},
+        {"T32K wave-rows cap2", 8, 11, 1, 2}, {"T32K wave-rows ident c4", 8, 11, 0, 4},
         {"R1 identity WRITE", 1, 3, 0, 0}, {"R8 eighth cap4 WRITE", 8, 3, 1, 4}, {"R8 eighth WRITE", 8, 3, 1, 0}, {"R8 eighth cap2 WRITE", 8, 3, 1, 2},
     };
     hipEvent_t ev[16];
     for (auto &e : ev) CK(hipEventCreate(&e));
     printf("# median ms per copy of %.3f GB (read) + the same written; %d placements\n", BYTES / 1e9, pairs);
     for (const Cfg &c : cfgs) {
-        if (brief && (c.wg != 0 || c.order >= 2)) continue;
+        if (brief && (c.wg != 0 || (c.order >= 2 && c.order < 10) || (c.map >> 4) != 0)) continue;
         if (brief && c.order < 2 && (c.map >> 4) == 0 && !(c.R == 8 && c.order == 0 && c.map == 1 && c.cap == 4) && !(c.R == 1 && c.cap == 0)) continue;
         printf("%-24s", c.name);
         for (auto &p : bufs) {
