@@ -881,8 +881,8 @@ __global__ __launch_bounds__(SVS_WG, kEmbedMinWaves<U>) void embed_kernel(const 
 //   * every lane loads (lanes past the end of the batch shadow its last block(s) and never store), so the row registers
 //     are defined on one path only: no copies at the joins (round 5: 173 static v_mov_b32, 61 of them on every wave's path);
 //   * a decided block costs 16 v_add_u32 instead of 192 conversion / add / saturating-conversion instructions; a WAVE in
-//     which some block could clip at 0 / 255 (a wave-uniform ballot) takes the saturating float form for all its lanes -
-//     same bytes, the old cost;
+//     which some block could clip at 0 / 255 (a wave-uniform ballot) takes a packed 16-bit saturating add for all its
+//     lanes - same bytes, 10 instructions per row dword;
 //   * the worklist deposit / collection moves rows as the 8-byte pairs they are held in.
 // Phases 2 and 3 as in embed_kernel.  gray and stego may alias.
 // ---------------------------------------------------------------------------------------
