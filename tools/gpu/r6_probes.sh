@@ -8,6 +8,7 @@
 #   stream    tools/probes/stream_probe: pure copies, R rows per lane x cap, tile map, order                                   -> r06_stream_probe.txt
 #   split     tools/probes/stream_probe 5 0 (every configuration): the R8 pattern's read and write streams apart, workgroup sizes, staggered XCD streams -> r06_stream_probe_split.txt
 #             (and `stream_probe 4 <kind> brief` for kind = 0..3: allocation kinds -> r06_alloc_kinds.txt)
+#   counters  tools/placement_probe.py under rocprofv3 --pmc (DRAM credit stalls, tag stalls; wait / VALU cycles), joined per pair            -> r06_placement_counters.txt
 #   caps      occupancy cap at n = 7 / general delta, odd block count per row, 1080p, n = 1; one block per lane                 -> r06_caps.txt
 # (the persistent, software-pipelined variant of the kernel - profiles/r06_stream_pipeline.txt - lived in the working tree between commits ac1b1d8 and a377b8d)
 set -u
@@ -27,6 +28,14 @@ pitch) for c in 4 0; do python tools/pitch_probe.py --pairs 4 --cap $c > $E/pitc
 stream) tools/probes/stream_probe 4 > $E/stream_probe.txt 2>&1; cat $E/stream_probe.txt ;;
 split) tools/probes/stream_probe 5 0 > $E/stream_probe_split.txt 2>&1; cat $E/stream_probe_split.txt
        for k in 0 1 2 3; do tools/probes/stream_probe 4 $k brief; done > $E/alloc_kinds.txt 2>&1 ;;
+counters) : > $E/placement_counters.txt
+       for pmc in "TCC_EA0_RDREQ_DRAM_CREDIT_STALL_sum TCC_EA0_WRREQ_DRAM_CREDIT_STALL_sum TCC_EA0_WRREQ_STALL_sum TCC_TAG_STALL_sum" "GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_VALU"; do
+         rm -rf $E/pc_run
+         rocprofv3 --kernel-trace --pmc $pmc --output-format csv -d $E/pc_run -- python tools/placement_probe.py --pairs 3 --reps 6 > $E/pc_probe.log 2>&1
+         grep -E "pair|#" $E/pc_probe.log | grep -v amdgpu >> $E/placement_counters.txt
+         python tools/placement_counters.py $E/pc_run 6 embed_row1_kernel >> $E/placement_counters.txt
+       done
+       rm -rf $E/pc_run; cat $E/placement_counters.txt ;;
 caps)  : > $E/caps.txt
        for cfg in "--frames 600 --n-ac 7 --delta 20" "--frames 600 --n-ac 3 --w 3848" "--frames 2400 --h 1080 --w 1920 --n-ac 3" "--frames 300 --h 1080 --w 1920 --n-ac 3" "--frames 600 --n-ac 1 --delta 10"; do
          echo "== $cfg" >> $E/caps.txt
@@ -35,5 +44,5 @@ caps)  : > $E/caps.txt
        echo "== one block per lane forced at W = 3840 (SVS_EMBED_BPL=1)" >> $E/caps.txt
        SVS_EMBED_BPL=1 python tools/ab_bench.py --frames 600 --n-ac 3 --rounds 7 --env-sweep SVS_EMBED_WG_PER_CU=0,4,6,8 $V/variants/libsvsdct_exp.so 2>&1 | grep -E "^SVS|^pattern|rror" >> $E/caps.txt
        cat $E/caps.txt ;;
-*) echo "usage: $0 place|maps|bpl|pitch|stream|split|caps"; exit 2 ;;
+*) echo "usage: $0 place|maps|bpl|pitch|stream|split|counters|caps"; exit 2 ;;
 esac
