@@ -166,7 +166,7 @@ def embed_kernel_label(mode: str, n_ac: int, delta: float) -> str:
     if not streaming:
         return "embed_exact_kernel (lane-per-block pocketfft arithmetic)"
     if rows == 1:
-        return "embed_row1_kernel (one launch: integer-domain cheap arithmetic + in-kernel exact replay of undecided blocks)"
+        return "embed_row1_kernel (one launch: integer-domain cheap arithmetic + in-kernel exact replay of undecided blocks; capped at 4 waves per SIMD)"
     return "embed_kernel<2> (one launch: two-row cheap arithmetic + in-kernel exact replay of undecided blocks)"
 
 
