@@ -64,6 +64,8 @@ def content(kind):
         gray.copy_(gray // 64)
     elif kind == "bright":
         gray.copy_(252 + gray // 64)
+    elif kind == "fullrange":  # uniform 0..255: some block of every wave can clip (the saturating store), 1.7 % replays
+        gray.copy_(torch.randint(0, 256, (F, H, W), dtype=torch.uint8, device=dev, generator=torch.Generator(device=dev).manual_seed(5)))
     else:
         raise SystemExit(f"unknown class {kind}")
 
