@@ -5,9 +5,9 @@ a property of WHERE the two 5 GB buffers landed (physical pages / fragment sizes
 In ONE process: several (cover, stego) pairs allocated in different ways, all kept alive so that every pair sits on different
 memory, the same embed launch timed on each with HIP events in sustained bursts.  If the time differs between pairs of one
 process, placement decides it; if every pair of a process runs at the same rate and processes differ, it is not the buffers.
-  torch      two torch.empty allocations per pair (what bench.py did through round 4)
+  torch      two torch.empty allocations per pair (what bench.py does)
   hipmalloc  two svs_malloc (hipMalloc) allocations per pair
-  arena      ONE svs_malloc for cover + stego + payload, 2 MB aligned sub-buffers (what bench.py does from round 5 on)
+  arena      ONE svs_malloc for cover + stego + payload, 2 MB aligned sub-buffers
 """
 import argparse
 import ctypes as C
