@@ -49,3 +49,13 @@ for e in ev:
 torch.cuda.synchronize()
 te = [e[0].elapsed_time(e[1]) for e in ev]; tx = [e[1].elapsed_time(e[2]) for e in ev]
 print(f"{mode:9s} gap {gap >> 20:5d} MB: embed {np.median(te):.4f} / {min(te):.4f}  extract {np.median(tx):.4f}   {g:#x} {s:#x} (stego - cover = {s - g:#x})")
+if "exp" in os.environ.get("SVSDCT_LIB", ""):      # experiments library: the same pair under other tile maps (0xFFFFFFFF = one eighth of the batch per XCD)
+    for em, xm in (("4294967295", "4294967295"), ("32", "32"), ("32", "4294967295")):
+        os.environ["SVS_EMBED_XCD_CHUNK"], os.environ["SVS_EXTRACT_XCD_CHUNK"] = em, xm
+        for e in ev:
+            e[0].record(); batch.embed_device(g, s, planes, delta, n, pay.data_ptr(), 0, cap, st)
+            e[1].record(); batch.extract_device(s, planes, delta, n, ext.data_ptr(), ext.numel(), st)
+            e[2].record()
+        torch.cuda.synchronize()
+        te = [e[0].elapsed_time(e[1]) for e in ev]; tx = [e[1].elapsed_time(e[2]) for e in ev]
+        print(f"    embed map {em:>10s}: {np.median(te):.4f}   extract map {xm:>10s}: {np.median(tx):.4f}")
