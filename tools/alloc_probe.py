@@ -3,7 +3,8 @@
   separate   two svs_malloc (hipMalloc) allocations                         (what two torch.empty calls amount to)
   arena      ONE svs_malloc for cover + stego, the stego plane 2 MB aligned behind the cover
   arena+gap  the same with <gap> MB between the two planes
-Prints the embed launch's median / min over `reps` (sustained) and the extract median.  usage: alloc_probe.py <mode> [gap_mb] [reps]"""
+Prints the embed launch's median / min over `reps` (sustained) and the extract median; with SVSDCT_LIB = the experiments library also the
+same pair under other embed / extract tile maps.  usage: alloc_probe.py <mode> [gap_mb] [reps]"""
 import ctypes as C, os, sys
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(REPO, "secure-video-steganography-using-ecc-and-dct_amd"))
