@@ -104,7 +104,7 @@ int svs_init(int device);
 int svs_device_arch(int device, char *buf, size_t buf_len);
 /* Releases the CALLING THREAD's staging context of the host-pointer entry points (svs_embed, svs_extract, svs_embed_bgr,
  * svs_extract_bgr, svs_embed_str, svs_extract_str): two streams and device buffers sized by the calls the thread makes (a
- * buffer above 64 MB that is more than four times what a call needs is given back at that call).  A thread's context is also
+ * buffer above 64 MB of which eight calls in a row used less than a quarter is given back).  A thread's context is also
  * released when the thread exits; calling any host-pointer entry point afterwards simply builds a new one.  The *_dev entry
  * points keep nothing. */
 int svs_shutdown(void);

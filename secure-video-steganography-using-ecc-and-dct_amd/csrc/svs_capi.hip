@@ -370,9 +370,10 @@ constexpr int kStageStreams = 2;      // st[0] = up (H2D copies + kernels), st[1
 constexpr int kChunkEvents = 32;      // "kernel of chunk k done" events, reused round-robin (a stream wait captures the
                                       // event's record at the time of the call, so re-recording one later is safe)
 
-struct Grow {   // device buffer of a staging context: grows on demand, shrinks when a call needs far less than it holds
+struct Grow {   // device buffer of a staging context: grows on demand, shrinks when calls keep needing far less than it holds
     void *p = nullptr;
     size_t cap = 0;
+    uint32_t oversized_calls = 0;   // consecutive calls that needed less than a quarter of it
 };
 constexpr size_t kStageKeepBytes = (size_t)64 << 20;   // a buffer up to this size is kept whatever the next call needs
 
@@ -421,9 +422,15 @@ int stage_acquire(HostStage **out) {
 
 int stage_reserve(Grow &g, size_t bytes) {
     const size_t want = (bytes + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);   // whole 2 MB pages
-    // enough, and not grossly more: a long-lived thread that once staged a multi-GB batch does not keep that HBM for good
-    //  - a buffer above 64 MB that is more than four times what this call needs is given back first
-    if (bytes <= g.cap && !(g.cap > kStageKeepBytes && g.cap / 4 > want)) return SVS_OK;
+    // enough, and not grossly more for long: a thread that once staged a multi-GB batch does not keep that HBM for good (ADVICE
+    // r05) - a buffer above 64 MB that eight calls in a row used less than a quarter of is given back (eight: a caller that
+    // alternates large and small batches must not pay a hipFree + hipMalloc per call)
+    if (bytes <= g.cap) {
+        const bool oversized = g.cap > kStageKeepBytes && g.cap / 4 > want;
+        g.oversized_calls = oversized ? g.oversized_calls + 1 : 0;
+        if (g.oversized_calls < 8) return SVS_OK;
+    }
+    g.oversized_calls = 0;
     if (g.p) { SVS_HIP(hipFree(g.p)); g.p = nullptr; g.cap = 0; }
     SVS_HIP(hipMalloc(&g.p, want));
     g.cap = want;

@@ -1300,3 +1300,30 @@ def test_one_row_integer_store_plain_and_saturating_waves_equal_the_oracle():
                 for mode in ("guarded", "exact"):
                     got, used = batch.embed_frames(frame, delta, n_ac, bits, mode=mode)
                     assert used == want_used and np.array_equal(got, want), (w, n_ac, delta, mode, int((got != want).sum()))
+
+
+def test_staging_buffers_shrink_after_a_run_of_small_calls():
+    """the per-thread staging context no longer keeps the device memory of the largest batch it ever moved - a
+    buffer above 64 MB that eight calls in a row used less than a quarter of is given back (and not before: a caller that
+    alternates large and small batches keeps it)."""
+    import torch
+    lib = native.load()
+    assert lib.svs_shutdown() == 0
+    big = synth.synthetic_frames(48, 1080, 1920, seed=1)               # 99.5 MB of frames
+    small = synth.synthetic_frames(1, 480, 640, seed=2)
+    bits_big = synth.synthetic_bits(batch.capacity_bits(48, 1080, 1920, 3), seed=3)
+    bits_small = synth.synthetic_bits(batch.capacity_bits(1, 480, 640, 3), seed=4)
+    free = lambda: torch.cuda.mem_get_info(0)[0]
+    batch.embed_frames(small, 8, 3, bits_small)                        # the context exists (streams, small buffers)
+    f0 = free()
+    batch.embed_frames(big, 8, 3, bits_big)
+    f1 = free()
+    assert f0 - f1 > 80 << 20, (f0, f1)                                # grew by the batch
+    for _ in range(4):
+        batch.embed_frames(small, 8, 3, bits_small)
+        batch.embed_frames(big, 8, 3, bits_big)                        # alternating: kept
+    assert free() <= f1 + (8 << 20)
+    for _ in range(9):
+        stego, used = batch.embed_frames(small, 8, 3, bits_small)
+    assert free() - f1 > 80 << 20, (f1, free())                        # given back after eight small calls in a row
+    assert used == bits_small.size
