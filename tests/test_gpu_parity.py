@@ -1306,14 +1306,19 @@ def test_staging_buffers_shrink_after_a_run_of_small_calls():
     """the per-thread staging context no longer keeps the device memory of the largest batch it ever moved - a
     buffer above 64 MB that eight calls in a row used less than a quarter of is given back (and not before: a caller that
     alternates large and small batches keeps it)."""
-    import torch
     lib = native.load()
     assert lib.svs_shutdown() == 0
+    hip = C.CDLL("libamdhip64.so")                                     # the runtime the library itself is linked against
+
+    def free():
+        a, b = C.c_size_t(0), C.c_size_t(0)
+        assert hip.hipMemGetInfo(C.byref(a), C.byref(b)) == 0
+        return a.value
+
     big = synth.synthetic_frames(48, 1080, 1920, seed=1)               # 99.5 MB of frames
     small = synth.synthetic_frames(1, 480, 640, seed=2)
     bits_big = synth.synthetic_bits(batch.capacity_bits(48, 1080, 1920, 3), seed=3)
     bits_small = synth.synthetic_bits(batch.capacity_bits(1, 480, 640, 3), seed=4)
-    free = lambda: torch.cuda.mem_get_info(0)[0]
     batch.embed_frames(small, 8, 3, bits_small)                        # the context exists (streams, small buffers)
     f0 = free()
     batch.embed_frames(big, 8, 3, bits_big)
